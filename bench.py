@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MFCC frames/sec at 16 kHz, 25 ms / 10 ms, nfft=512, 40 mel, 13 cep
+(BASELINE.json `metric`), on BASELINE.json configs[1]:
+
+    one step = one pass of the hot path over a batch of 1024 synthetic 1 s utterances
+               -> [1024*99, 39] = MFCC | delta | delta-delta   (dsp_mfcc_delta_batch, C ABI)
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Inputs are resident in HBM before the timed region; successive steps rotate over distinct input
+batches whose total size exceeds the 256 MiB Infinity Cache, so reads come from HBM.  Utterances
+shard across ranks with no data-path collective (weak scaling: every rank owns its own batches);
+the RCCL all-gather of one step's features (configs[2]) is timed separately and reported under
+"gather" -- it is not part of `value`.
+
+rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'dsp-speech-recognition_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+CFG = dict(samplerate=16000, winlen=0.025, winstep=0.01, numcep=13, nfilt=40, nfft=512, lowfreq=0,
+           highfreq=None, preemph=0.97, ceplifter=22, appendEnergy=True)
+DELTA_N = 2
+B, N = 1024, 16000              # utterances per step, samples per utterance (1 s @ 16 kHz)
+T = 99                          # frames per utterance: 1 + ceil((16000-400)/160)
+BYTES_PER_FRAME_MFCC = 4.0 * N / T + 4.0 * 13        # 698.5: fp32 wave read once + 13 fp32 out
+BYTES_PER_FRAME_ALL = 4.0 * N / T + 4.0 * 39         # 802.5: SURVEY 8d, MFCC+delta+delta2
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def synth_batch(seed):
+    """Class-A throughput signal of SURVEY 8d: 0.25 * N(0,1), fp32."""
+    rng = np.random.default_rng(1_000_003 * 17 + seed)
+    return (0.25 * rng.standard_normal((B, N), dtype=np.float32)).astype(np.float32)
+
+
+def _oracle_worker(args):
+    seed, count = args
+    from oracle import dsp_oracle
+    x = synth_batch(seed)[:count].astype(np.float64)
+    t0 = time.perf_counter()
+    for b in range(count):
+        dsp_oracle.mfcc_delta(x[b], delta_n=DELTA_N, winfunc=np.hamming, **CFG)
+    return time.perf_counter() - t0, count * T
+
+
+def cpu_baseline(budget_s=12.0):
+    """The NumPy oracle (parity-pinned port of the reference's path) timed on this box's host cores
+    on a bounded sample of the same workload: all cores via multiprocessing, plus 1 core."""
+    import multiprocessing as mp
+    os.environ.setdefault('OMP_NUM_THREADS', '1')
+    os.environ.setdefault('OPENBLAS_NUM_THREADS', '1')
+    dt, frames = _oracle_worker((0, 64))           # calibrate on 64 utterances, single core
+    per_utt = dt / 64
+    single = frames / dt
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 64))
+    per_worker = int(max(16, min(B, budget_s / per_utt)))
+    ctx = mp.get_context('spawn')
+    with ctx.Pool(cores) as pool:
+        pool.map(_oracle_worker, [(i, 2) for i in range(cores)])   # warm the workers (imports)
+        t0 = time.perf_counter()
+        res = pool.map(_oracle_worker, [(100 + i, per_worker) for i in range(cores)])
+        wall = time.perf_counter() - t0
+    total_frames = sum(r[1] for r in res)
+    return {
+        'value': total_frames / wall, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+        'sample': f'{cores} workers x {per_worker} utterances (1 s, 16 kHz) of the same synthetic '
+                  f'workload, NumPy oracle mfcc+delta+delta2, wall {wall:.1f} s',
+        'single_core_value': single,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=400)
+    ap.add_argument('--warmup', type=int, default=40)
+    ap.add_argument('--buffers', type=int, default=8, help='distinct input batches rotated over (x65.5 MB)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-gather', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from features import _native as nat
+    from features.batch import FeaturePlan
+    nat.check(nat.load().dsp_set_device(local_rank))
+
+    plan = FeaturePlan(winfunc=np.hamming, **CFG)
+    layout = plan.layout(np.empty((B, N), dtype=np.float32))
+    assert layout.total_frames == B * T
+    D = plan.width(DELTA_N)
+
+    host0 = synth_batch(rank * 1000)
+    waves = [torch.from_numpy(host0).to(dev)]
+    for i in range(1, args.buffers):
+        waves.append(torch.from_numpy(synth_batch(rank * 1000 + i)).to(dev))
+    outs = [torch.empty((B * T, D), dtype=torch.float32, device=dev) for _ in range(min(args.buffers, 4))]
+    stream = torch.cuda.current_stream(dev)
+    sp = stream.cuda_stream
+
+    def step(i):
+        plan.run_raw(waves[i % len(waves)].data_ptr(), nat.WAVE_F32, layout, outs[i % len(outs)].data_ptr(),
+                     DELTA_N, sp)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # --- dominant kernel (fused MFCC) timed alone with events on the launch stream, same rotation ---
+    lib = nat.load()
+
+    def mfcc_only(i):
+        nat.check(lib.dsp_features_batch(plan.plan.handle, waves[i % len(waves)].data_ptr(), nat.WAVE_F32, None,
+                                         None, B, B * T, N, nat.OUT_MFCC, outs[i % len(outs)].data_ptr(), D,
+                                         None, sp))
+
+    ksteps = max(10, min(args.steps, 200))
+    for i in range(5):
+        mfcc_only(i)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    ev0.record(stream)
+    for i in range(ksteps):
+        mfcc_only(i)
+    ev1.record(stream)
+    torch.cuda.synchronize(dev)
+    kernel_ms = ev0.elapsed_time(ev1) / ksteps
+
+    # --- parity guard on batch 0 (outside the timed region): HIP path vs the CPU oracle ---
+    parity = None
+    if rank == 0:
+        from oracle import dsp_oracle
+        step(0)
+        torch.cuda.synchronize(dev)
+        got = outs[0].cpu().numpy().reshape(B, T, D)
+        parity = 0.0
+        for b in (0, 1, B // 2, B - 1):
+            ref = dsp_oracle.mfcc_delta(host0[b].astype(np.float64), delta_n=DELTA_N, winfunc=np.hamming, **CFG)
+            parity = max(parity, float(np.max(np.abs(got[b] - ref)) / np.max(np.abs(ref))))
+
+    # --- configs[2]: RCCL all-gather of one step's features, timed on its own ---
+    gather = None
+    if world > 1 and not args.no_gather:
+        gbuf = torch.empty((world, B * T, D), dtype=torch.float32, device=dev)
+        for _ in range(2):
+            dist.all_gather_into_tensor(gbuf, outs[0])
+        sync_all()
+        g0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            dist.all_gather_into_tensor(gbuf, outs[0])
+        sync_all()
+        gms = (time.perf_counter() - g0) / reps * 1e3
+        gather = {'collective': 'rccl all_gather_into_tensor', 'bytes_per_rank': B * T * D * 4, 'ms': gms,
+                  'algbw_GBps': world * B * T * D * 4 / gms / 1e6}
+
+    frames_total = float(world) * B * T * args.steps
+    value = frames_total / dt
+    achieved = BYTES_PER_FRAME_MFCC * B * T / (kernel_ms * 1e-3) / 1e9
+    res = {
+        'metric': 'MFCC frames/sec at 16 kHz, 25 ms/10 ms, nfft=512, 40 mel, 13 cep',
+        'value': value, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'configs[1]: batch of 1024 synthetic 1 s 16 kHz utterances -> MFCC+delta+delta2 '
+                               '[1024*99, 39] per step per GPU', 'utterances_per_step_per_gpu': B,
+                   'frames_per_utterance': T, 'delta_n': DELTA_N, 'input_buffers_rotated': len(waves),
+                   'sharding': f'{world} ranks x independent batches, no data-path collective'},
+        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+                     'kernel': 'fused MFCC kernel (dsp_features_batch, DSP_OUT_MFCC)',
+                     'kernel_ms': kernel_ms, 'bytes_per_frame': BYTES_PER_FRAME_MFCC,
+                     'frames_per_launch': B * T,
+                     'whole_step_GBps': BYTES_PER_FRAME_ALL * value / world / 1e9},
+        'parity_normwise_vs_oracle': parity,
+    }
+    if gather is not None:
+        res['gather'] = gather
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res['cpu_baseline'] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

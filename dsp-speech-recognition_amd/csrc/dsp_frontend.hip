@@ -1,0 +1,394 @@
+// C ABI of libdsp_frontend.so (see include/dsp_frontend.h).  gfx950 / ROCm only.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "dsp_common.h"
+#include "kernels_generic.h"
+#include "kernels_fast512.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(DSP_EHIP, "%s: %s", #expr, hipGetErrorString(e_));  \
+    } while (0)
+
+template <typename T>
+int upload(T** d, const T* h, size_t n) {
+    *d = nullptr;
+    if (n == 0) return DSP_OK;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(d), n * sizeof(T)));
+    HIP_TRY(hipMemcpy(*d, h, n * sizeof(T), hipMemcpyHostToDevice));
+    return DSP_OK;
+}
+
+int grid_for(int64_t work_items, int per_block) {
+    int64_t blocks = (work_items + per_block - 1) / per_block;
+    if (blocks < 1) blocks = 1;
+    const int64_t cap = 256 * 8;  // 256 CUs x 8 resident blocks; the kernels grid-stride beyond
+    return (int)(blocks < cap ? blocks : cap);
+}
+
+bool factor_half_fft(int n2, std::vector<int>& radix) {
+    radix.clear();
+    if (n2 % 3 == 0) { radix.push_back(3); n2 /= 3; }
+    while (n2 % 4 == 0) { radix.push_back(4); n2 /= 4; }
+    if (n2 % 2 == 0) { radix.push_back(2); n2 /= 2; }
+    return n2 == 1 && radix.size() <= DSP_MAX_RADIX_PASSES;
+}
+
+int check_geom(const void* d_wave, int wave_dtype, const int64_t* d_sample_offsets,
+               const int64_t* d_frame_offsets, int32_t n_utt, int64_t n_frames_total,
+               int64_t uniform_samples) {
+    if (!d_wave) return fail(DSP_EINVAL, "d_wave is NULL");
+    if (wave_dtype != DSP_WAVE_F32 && wave_dtype != DSP_WAVE_I16)
+        return fail(DSP_EINVAL, "unsupported wave_dtype %d", wave_dtype);
+    if (n_utt <= 0 || n_frames_total <= 0) return fail(DSP_EINVAL, "empty batch (n_utt=%d, frames=%lld)", n_utt, (long long)n_frames_total);
+    if (uniform_samples <= 0 && (!d_sample_offsets || !d_frame_offsets))
+        return fail(DSP_EINVAL, "ragged batch needs d_sample_offsets and d_frame_offsets");
+    return DSP_OK;
+}
+
+BatchGeom make_geom(const int64_t* d_sample_offsets, const int64_t* d_frame_offsets, int32_t n_utt,
+                    int64_t n_frames_total, int64_t uniform_samples, int32_t L, int32_t S) {
+    BatchGeom bg;
+    bg.sample_off = d_sample_offsets;
+    bg.frame_off = d_frame_offsets;
+    bg.uniform_samples = uniform_samples > 0 ? uniform_samples : 0;
+    bg.uniform_frames = 0;
+    if (uniform_samples > 0) {
+        int64_t T;
+        dsp_frame_count(uniform_samples, L, S, &T);
+        bg.uniform_frames = T;
+    }
+    bg.total_frames = n_frames_total;
+    bg.n_utt = n_utt;
+    return bg;
+}
+
+GenericParams generic_params(const dsp_plan* p) {
+    GenericParams P;
+    memset(&P, 0, sizeof(P));
+    P.L = p->L; P.S = p->S; P.nfft = p->nfft; P.K = p->K; P.M = p->M; P.C = p->C;
+    P.lfft = p->lfft; P.append_energy = p->append_energy; P.preemph = p->preemph;
+    P.window = p->d_window; P.tw = p->d_twiddle;
+    P.mel_start = p->d_mel_start; P.mel_count = p->d_mel_count; P.mel_off = p->d_mel_off;
+    P.mel_w = p->d_mel_w; P.dct = p->d_dct;
+    std::vector<int> radix;
+    factor_half_fft(p->nfft / 2, radix);
+    P.n_pass = (int)radix.size();
+    for (int i = 0; i < P.n_pass; ++i) P.radix[i] = radix[i];
+    return P;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dsp_abi_version(void) { return DSP_ABI_VERSION; }
+
+const char* dsp_last_error(void) { return g_err.c_str(); }
+
+int dsp_device_count(int* n) {
+    if (!n) return fail(DSP_EINVAL, "n is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; return fail(DSP_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *n = c;
+    return DSP_OK;
+}
+
+int dsp_set_device(int device) {
+    HIP_TRY(hipSetDevice(device));
+    return DSP_OK;
+}
+
+int dsp_malloc(void** d_ptr, size_t bytes) {
+    if (!d_ptr) return fail(DSP_EINVAL, "d_ptr is NULL");
+    HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 1));
+    return DSP_OK;
+}
+
+int dsp_free(void* d_ptr) {
+    if (d_ptr) HIP_TRY(hipFree(d_ptr));
+    return DSP_OK;
+}
+
+int dsp_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream) {
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return DSP_OK;
+}
+
+int dsp_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream) {
+    HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return DSP_OK;
+}
+
+int dsp_memset(void* d_dst, int value, size_t bytes, void* stream) {
+    HIP_TRY(hipMemsetAsync(d_dst, value, bytes, (hipStream_t)stream));
+    return DSP_OK;
+}
+
+int dsp_stream_synchronize(void* stream) {
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return DSP_OK;
+}
+
+int dsp_frame_count(int64_t n_samples, int32_t frame_len, int32_t frame_step, int64_t* n_frames) {
+    if (!n_frames || frame_len <= 0 || frame_step <= 0 || n_samples < 0)
+        return fail(DSP_EINVAL, "dsp_frame_count: bad arguments");
+    if (n_samples <= frame_len) *n_frames = 1;
+    else *n_frames = 1 + (n_samples - frame_len + frame_step - 1) / frame_step;
+    return DSP_OK;
+}
+
+int dsp_frame_offsets(const int64_t* h_sample_offsets, int32_t n_utt, int32_t frame_len,
+                      int32_t frame_step, int64_t* h_frame_offsets) {
+    if (!h_sample_offsets || !h_frame_offsets || n_utt < 0)
+        return fail(DSP_EINVAL, "dsp_frame_offsets: bad arguments");
+    h_frame_offsets[0] = 0;
+    for (int32_t b = 0; b < n_utt; ++b) {
+        int64_t T;
+        const int64_t n = h_sample_offsets[b + 1] - h_sample_offsets[b];
+        if (n < 0) return fail(DSP_EINVAL, "sample_offsets not monotone at %d", b);
+        int rc = dsp_frame_count(n, frame_len, frame_step, &T);
+        if (rc != DSP_OK) return rc;
+        h_frame_offsets[b + 1] = h_frame_offsets[b] + T;
+    }
+    return DSP_OK;
+}
+
+int dsp_plan_create(const dsp_plan_desc* d, dsp_plan** out) {
+    if (!d || !out) return fail(DSP_EINVAL, "NULL desc/out");
+    *out = nullptr;
+    if (d->frame_len <= 0 || d->frame_step <= 0) return fail(DSP_EINVAL, "frame_len/frame_step must be > 0");
+    std::vector<int> radix;
+    if (d->nfft < 16 || d->nfft > 4096 || (d->nfft & 1) || !factor_half_fft(d->nfft / 2, radix))
+        return fail(DSP_EINVAL, "unsupported nfft %d (need 2^k or 3*2^k in [16, 4096])", d->nfft);
+    if (!d->h_window) return fail(DSP_EINVAL, "h_window is NULL");
+    if (d->nfilt < 0 || d->numcep < 0 || d->numcep > d->nfilt)
+        return fail(DSP_EINVAL, "need 0 <= numcep <= nfilt (got %d, %d)", d->numcep, d->nfilt);
+    if (d->nfilt > d->nfft) return fail(DSP_EINVAL, "nfilt %d > nfft %d", d->nfilt, d->nfft);
+    const int K = d->nfft / 2 + 1;
+    std::vector<int32_t> off(d->nfilt > 0 ? d->nfilt : 1, 0);
+    int64_t nnz = 0;
+    if (d->nfilt > 0) {
+        if (!d->h_mel_start || !d->h_mel_count || !d->h_mel_weights)
+            return fail(DSP_EINVAL, "mel tables missing");
+        if (d->numcep > 0 && !d->h_dct) return fail(DSP_EINVAL, "h_dct is NULL");
+        for (int j = 0; j < d->nfilt; ++j) {
+            if (d->h_mel_count[j] < 0 || d->h_mel_start[j] < 0 || d->h_mel_start[j] + d->h_mel_count[j] > K)
+                return fail(DSP_EINVAL, "mel filter %d spans bins outside [0,%d)", j, K);
+            off[j] = (int32_t)nnz;
+            nnz += d->h_mel_count[j];
+        }
+    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    dsp_plan* p = new dsp_plan();
+    memset(p, 0, sizeof(*p));
+    p->L = d->frame_len; p->S = d->frame_step; p->nfft = d->nfft; p->K = K;
+    p->M = d->nfilt; p->C = d->numcep; p->append_energy = d->append_energy ? 1 : 0;
+    p->lfft = d->frame_len < d->nfft ? d->frame_len : d->nfft;
+    p->preemph = d->preemph; p->mel_nnz = (int32_t)nnz; p->device = dev;
+    std::vector<float2> tw(d->nfft);
+    for (int k = 0; k < d->nfft; ++k) {
+        const double a = -2.0 * M_PI * (double)k / (double)d->nfft;
+        tw[k] = make_float2((float)cos(a), (float)sin(a));
+    }
+    int rc = DSP_OK;
+    if (rc == DSP_OK) rc = upload(&p->d_window, d->h_window, (size_t)d->frame_len);
+    if (rc == DSP_OK) rc = upload(&p->d_twiddle, tw.data(), tw.size());
+    if (rc == DSP_OK && d->nfilt > 0) {
+        rc = upload(&p->d_mel_start, d->h_mel_start, (size_t)d->nfilt);
+        if (rc == DSP_OK) rc = upload(&p->d_mel_count, d->h_mel_count, (size_t)d->nfilt);
+        if (rc == DSP_OK) rc = upload(&p->d_mel_off, off.data(), (size_t)d->nfilt);
+        if (rc == DSP_OK) rc = upload(&p->d_mel_w, d->h_mel_weights, (size_t)nnz);
+        if (rc == DSP_OK && d->numcep > 0) rc = upload(&p->d_dct, d->h_dct, (size_t)d->numcep * d->nfilt);
+    }
+    if (rc == DSP_OK) rc = fast512_plan_init(p, d, off.data());
+    if (rc != DSP_OK) { dsp_plan_destroy(p); return rc; }
+    *out = p;
+    return DSP_OK;
+}
+
+int dsp_plan_destroy(dsp_plan* p) {
+    if (!p) return DSP_OK;
+    void* bufs[] = {p->d_window, p->d_twiddle, p->d_mel_start, p->d_mel_count, p->d_mel_off, p->d_mel_w, p->d_dct};
+    for (void* b : bufs) (void)hipFree(b);
+    fast512_plan_free(p);
+    delete p;
+    return DSP_OK;
+}
+
+int dsp_preemphasis_batch(const void* d_wave, int wave_dtype, const int64_t* d_sample_offsets,
+                          int32_t n_utt, int64_t n_samples_total, float coeff, float* d_out, void* stream) {
+    if (!d_wave || !d_out || !d_sample_offsets || n_utt <= 0 || n_samples_total <= 0)
+        return fail(DSP_EINVAL, "dsp_preemphasis_batch: bad arguments");
+    const int grid = grid_for(n_samples_total, 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (wave_dtype == DSP_WAVE_I16)
+        preemphasis_kernel<DSP_WAVE_I16><<<grid, 256, 0, st>>>(d_wave, d_sample_offsets, n_utt, n_samples_total, coeff, d_out);
+    else if (wave_dtype == DSP_WAVE_F32)
+        preemphasis_kernel<DSP_WAVE_F32><<<grid, 256, 0, st>>>(d_wave, d_sample_offsets, n_utt, n_samples_total, coeff, d_out);
+    else
+        return fail(DSP_EINVAL, "unsupported wave_dtype %d", wave_dtype);
+    HIP_TRY(hipGetLastError());
+    return DSP_OK;
+}
+
+static int launch_generic(const dsp_plan* plan, const void* d_wave, int wave_dtype, const BatchGeom& bg,
+                          int out_kind, float* d_out, int64_t ld_out, float* d_out2, hipStream_t st) {
+    GenericParams P = generic_params(plan);
+    const size_t lds = (size_t)DSP_GEN_WAVES * 2 * (plan->nfft / 2) * sizeof(float2);
+    const int grid = grid_for(bg.total_frames, DSP_GEN_WAVES);
+    if (wave_dtype == DSP_WAVE_I16) {
+        if (lds > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void*)features_generic_kernel<DSP_WAVE_I16>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        features_generic_kernel<DSP_WAVE_I16><<<grid, 64 * DSP_GEN_WAVES, lds, st>>>(P, bg, d_wave, out_kind, d_out, ld_out, d_out2);
+    } else {
+        if (lds > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void*)features_generic_kernel<DSP_WAVE_F32>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        features_generic_kernel<DSP_WAVE_F32><<<grid, 64 * DSP_GEN_WAVES, lds, st>>>(P, bg, d_wave, out_kind, d_out, ld_out, d_out2);
+    }
+    HIP_TRY(hipGetLastError());
+    return DSP_OK;
+}
+
+int dsp_features_batch(const dsp_plan* plan, const void* d_wave, int wave_dtype,
+                       const int64_t* d_sample_offsets, const int64_t* d_frame_offsets, int32_t n_utt,
+                       int64_t n_frames_total, int64_t uniform_samples, int out_kind, float* d_out,
+                       int64_t ld_out, float* d_out2, void* stream) {
+    if (!plan || !d_out) return fail(DSP_EINVAL, "plan/d_out is NULL");
+    int rc = check_geom(d_wave, wave_dtype, d_sample_offsets, d_frame_offsets, n_utt, n_frames_total, uniform_samples);
+    if (rc != DSP_OK) return rc;
+    int width;
+    switch (out_kind) {
+        case DSP_OUT_FRAMES: width = plan->L; break;
+        case DSP_OUT_MAGSPEC:
+        case DSP_OUT_POWSPEC: width = plan->K; break;
+        case DSP_OUT_FBANK:
+            width = plan->M;
+            if (plan->M <= 0) return fail(DSP_EINVAL, "plan has no mel filterbank");
+            if (!d_out2) return fail(DSP_EINVAL, "DSP_OUT_FBANK needs d_out2 (energy)");
+            break;
+        case DSP_OUT_MFCC:
+            width = plan->C;
+            if (plan->M <= 0 || plan->C <= 0) return fail(DSP_EINVAL, "plan has no mel/DCT tables");
+            break;
+        default: return fail(DSP_EINVAL, "unknown out_kind %d", out_kind);
+    }
+    if (ld_out == 0) ld_out = width;
+    if (ld_out < width) return fail(DSP_EINVAL, "ld_out %lld < row width %d", (long long)ld_out, width);
+    BatchGeom bg = make_geom(d_sample_offsets, d_frame_offsets, n_utt, n_frames_total, uniform_samples, plan->L, plan->S);
+    if (uniform_samples > 0 && bg.uniform_frames * n_utt != n_frames_total)
+        return fail(DSP_EINVAL, "n_frames_total %lld != n_utt*T (%d*%lld)", (long long)n_frames_total, n_utt, (long long)bg.uniform_frames);
+    hipStream_t st = (hipStream_t)stream;
+    if (out_kind == DSP_OUT_MFCC && fast512_applicable(plan))
+        return fast512_launch(plan, d_wave, wave_dtype, bg, d_out, ld_out, st);
+    return launch_generic(plan, d_wave, wave_dtype, bg, out_kind, d_out, ld_out, d_out2, st);
+}
+
+int dsp_delta_batch(const float* d_in, int64_t ld_in, const int64_t* d_frame_offsets, int32_t n_utt,
+                    int64_t n_frames_total, int64_t uniform_frames, int32_t D, int32_t N, float* d_out,
+                    int64_t ld_out, float* d_out_dd, int64_t ld_out_dd, void* stream) {
+    if (!d_in || !d_out) return fail(DSP_EINVAL, "dsp_delta_batch: NULL buffer");
+    if (N < 1) return fail(DSP_EINVAL, "N must be an integer >= 1");  // base.py:71-72
+    if (D <= 0 || n_utt <= 0 || n_frames_total <= 0) return fail(DSP_EINVAL, "dsp_delta_batch: empty input");
+    if (uniform_frames <= 0 && !d_frame_offsets) return fail(DSP_EINVAL, "ragged batch needs d_frame_offsets");
+    if (ld_in == 0) ld_in = D;
+    if (ld_out == 0) ld_out = D;
+    if (ld_out_dd == 0) ld_out_dd = D;
+    BatchGeom bg;
+    memset(&bg, 0, sizeof(bg));
+    bg.frame_off = d_frame_offsets;
+    bg.uniform_frames = uniform_frames > 0 ? uniform_frames : 0;
+    bg.total_frames = n_frames_total;
+    bg.n_utt = n_utt;
+    int den = 0;
+    for (int i = 1; i <= N; ++i) den += i * i;
+    const float inv_den = (float)(1.0 / (2.0 * den));
+    delta_kernel<<<grid_for(n_frames_total * D, 256), 256, 0, (hipStream_t)stream>>>(
+        d_in, ld_in, bg, D, N, inv_den, d_out, ld_out, d_out_dd, ld_out_dd);
+    HIP_TRY(hipGetLastError());
+    return DSP_OK;
+}
+
+int dsp_mfcc_delta_batch(const dsp_plan* plan, const void* d_wave, int wave_dtype,
+                         const int64_t* d_sample_offsets, const int64_t* d_frame_offsets, int32_t n_utt,
+                         int64_t n_frames_total, int64_t uniform_samples, int32_t delta_n, float* d_out,
+                         void* stream) {
+    if (!plan) return fail(DSP_EINVAL, "plan is NULL");
+    const int C = plan->C;
+    int rc = dsp_features_batch(plan, d_wave, wave_dtype, d_sample_offsets, d_frame_offsets, n_utt,
+                                n_frames_total, uniform_samples, DSP_OUT_MFCC, d_out, 3 * (int64_t)C, nullptr, stream);
+    if (rc != DSP_OK) return rc;
+    int64_t uniform_frames = 0;
+    if (uniform_samples > 0) dsp_frame_count(uniform_samples, plan->L, plan->S, &uniform_frames);
+    return dsp_delta_batch(d_out, 3 * (int64_t)C, d_frame_offsets, n_utt, n_frames_total, uniform_frames, C,
+                           delta_n, d_out + C, 3 * (int64_t)C, d_out + 2 * C, 3 * (int64_t)C, stream);
+}
+
+int dsp_scale_columns(float* d_x, int64_t rows, int32_t cols, const float* d_scale, void* stream) {
+    if (!d_x || !d_scale || rows <= 0 || cols <= 0) return fail(DSP_EINVAL, "dsp_scale_columns: bad arguments");
+    scale_columns_kernel<<<grid_for(rows * cols, 256), 256, 0, (hipStream_t)stream>>>(d_x, rows, cols, d_scale);
+    HIP_TRY(hipGetLastError());
+    return DSP_OK;
+}
+
+int dsp_vad_features_batch(const void* d_wave, int wave_dtype, const int64_t* d_sample_offsets,
+                           const int64_t* d_frame_offsets, int32_t n_utt, int64_t n_frames_total,
+                           int64_t uniform_samples, int32_t frame_len, int32_t frame_step, int32_t use_sq,
+                           double* d_amp_sum, int32_t* d_zcr, void* stream) {
+    if (!d_amp_sum || !d_zcr) return fail(DSP_EINVAL, "dsp_vad_features_batch: NULL output");
+    if (frame_len <= 0 || frame_step <= 0) return fail(DSP_EINVAL, "frame_len/frame_step must be > 0");
+    int rc = check_geom(d_wave, wave_dtype, d_sample_offsets, d_frame_offsets, n_utt, n_frames_total, uniform_samples);
+    if (rc != DSP_OK) return rc;
+    BatchGeom bg = make_geom(d_sample_offsets, d_frame_offsets, n_utt, n_frames_total, uniform_samples, frame_len, frame_step);
+    const int grid = grid_for(n_frames_total, 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (wave_dtype == DSP_WAVE_I16)
+        vad_features_kernel<DSP_WAVE_I16><<<grid, 256, 0, st>>>(d_wave, bg, frame_len, frame_step, use_sq, d_amp_sum, d_zcr);
+    else
+        vad_features_kernel<DSP_WAVE_F32><<<grid, 256, 0, st>>>(d_wave, bg, frame_len, frame_step, use_sq, d_amp_sum, d_zcr);
+    HIP_TRY(hipGetLastError());
+    return DSP_OK;
+}
+
+int dsp_endpoint_rule_batch(const double* d_amp_sum, const int32_t* d_zcr, const int64_t* d_frame_offsets,
+                            int32_t n_utt, int32_t frame_len, double cfg_frame, double cfg_step,
+                            int32_t* d_endpoints, void* stream) {
+    if (!d_amp_sum || !d_zcr || !d_frame_offsets || !d_endpoints || n_utt <= 0 || frame_len <= 0)
+        return fail(DSP_EINVAL, "dsp_endpoint_rule_batch: bad arguments");
+    if (!(cfg_frame > 0.0) || !(cfg_step > 0.0)) return fail(DSP_EINVAL, "cfg.frame / cfg.step must be > 0");
+    if (2 * (int)(0.100 / cfg_step) > DSP_MAX_SIL)
+        return fail(DSP_EINVAL, "cfg.step %g gives a silence window > %d frames", cfg_step, DSP_MAX_SIL);
+    endpoint_rule_kernel<<<(n_utt + 63) / 64, 64, 0, (hipStream_t)stream>>>(
+        d_amp_sum, d_zcr, d_frame_offsets, n_utt, frame_len, cfg_frame, cfg_step, d_endpoints);
+    HIP_TRY(hipGetLastError());
+    return DSP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,373 @@
+// Generic (table-driven, any supported NFFT / L / S / M / C) kernels of the feature path.
+// One wavefront owns one frame: frame samples -> LDS, mixed-radix Stockham FFT of NFFT/2 complex
+// points in LDS (radices 4/2 plus one optional 3 for NFFT = 3*2^k, e.g. model.py:74's 1536),
+// real-spectrum untangle, |X|^2/NFFT, CSR mel triangles, log, DCT*lifter, energy swap.
+// This is the correctness workhorse and the fallback for every configuration the specialised
+// NFFT=512 kernel (kernels_fast512.h) does not cover.
+#pragma once
+
+#include "dsp_common.h"
+
+#define DSP_GEN_WAVES 4
+#define DSP_MAX_RADIX_PASSES 12
+
+struct GenericParams {
+    int32_t L, S, nfft, K, M, C, lfft, append_energy;
+    float preemph;
+    const float* window;
+    const float2* tw;  // [nfft] exp(-2 pi i k / nfft)
+    const int32_t* mel_start;
+    const int32_t* mel_count;
+    const int32_t* mel_off;
+    const float* mel_w;
+    const float* dct;
+    int32_t n_pass;
+    int32_t radix[DSP_MAX_RADIX_PASSES];
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+
+// One Stockham pass of radix R over n complex points held in LDS (in -> out), executed by one wave.
+// p = product of the radices of the previous passes.  Thread j handles inputs j + r*n/R.
+template <int R>
+__device__ __forceinline__ void stockham_pass(const float2* __restrict__ in, float2* __restrict__ out, int n,
+                                              int p, int lane, const float2* __restrict__ tw, int nfft) {
+    const int T = n / R;
+    const int twstep = nfft / (p * R);  // exp(-2 pi i r k /(p R)) = tw[r * k * twstep]
+    for (int j = lane; j < T; j += 64) {
+        const int k = j % p;
+        float2 u[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float2 v = in[j + r * T];
+            if (r > 0 && k > 0) v = cmul(v, tw[r * k * twstep]);
+            u[r] = v;
+        }
+        const int j0 = (j - k) * R + k;
+        if constexpr (R == 2) {
+            out[j0] = make_float2(u[0].x + u[1].x, u[0].y + u[1].y);
+            out[j0 + p] = make_float2(u[0].x - u[1].x, u[0].y - u[1].y);
+        } else if constexpr (R == 3) {
+            const float h = 0.86602540378443864676f;  // sqrt(3)/2
+            float2 t1 = make_float2(u[1].x + u[2].x, u[1].y + u[2].y);
+            float2 t2 = make_float2(fmaf(-0.5f, t1.x, u[0].x), fmaf(-0.5f, t1.y, u[0].y));
+            float2 t3 = make_float2(h * (u[1].x - u[2].x), h * (u[1].y - u[2].y));
+            out[j0] = make_float2(u[0].x + t1.x, u[0].y + t1.y);
+            out[j0 + p] = make_float2(t2.x + t3.y, t2.y - t3.x);
+            out[j0 + 2 * p] = make_float2(t2.x - t3.y, t2.y + t3.x);
+        } else {  // R == 4, forward: W4 = -i
+            float2 a = make_float2(u[0].x + u[2].x, u[0].y + u[2].y);
+            float2 b = make_float2(u[0].x - u[2].x, u[0].y - u[2].y);
+            float2 c = make_float2(u[1].x + u[3].x, u[1].y + u[3].y);
+            float2 d = make_float2(u[1].x - u[3].x, u[1].y - u[3].y);
+            out[j0] = make_float2(a.x + c.x, a.y + c.y);
+            out[j0 + p] = make_float2(b.x + d.y, b.y - d.x);      // b - i d
+            out[j0 + 2 * p] = make_float2(a.x - c.x, a.y - c.y);
+            out[j0 + 3 * p] = make_float2(b.x - d.y, b.y + d.x);  // b + i d
+        }
+    }
+}
+
+template <int DTYPE>
+__global__ __launch_bounds__(64 * DSP_GEN_WAVES) void features_generic_kernel(
+    GenericParams P, BatchGeom bg, const void* __restrict__ wave, int out_kind, float* __restrict__ out,
+    int64_t ld_out, float* __restrict__ out2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int N2 = P.nfft >> 1;
+    float2* bufA = reinterpret_cast<float2*>(smem) + (size_t)wid * 2 * N2;
+    float2* bufB = bufA + N2;
+
+    const int64_t n_tiles = (bg.total_frames + DSP_GEN_WAVES - 1) / DSP_GEN_WAVES;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        int64_t g = tile * DSP_GEN_WAVES + wid;
+        const bool active = g < bg.total_frames;
+        if (!active) g = bg.total_frames - 1;  // keep the wave in step with the barriers
+        int32_t utt;
+        int64_t t, s0, nsamp;
+        dsp_locate(bg, g, utt, t, s0, nsamp);
+        const int64_t first = t * (int64_t)P.S;
+
+        // ---- pre-emphasis + framing + window (sigproc.py:66-98,178-185) ----
+        float* fr = reinterpret_cast<float*>(bufA);
+        for (int n = lane; n < P.L; n += 64) {
+            const int64_t pos = first + n;
+            float v = 0.f;
+            if (pos < nsamp) {
+                v = dsp_load_sample<DTYPE>(wave, s0 + pos);
+                if (P.preemph != 0.f && pos > 0)
+                    v = fmaf(-P.preemph, dsp_load_sample<DTYPE>(wave, s0 + pos - 1), v);
+            }
+            v *= P.window[n];
+            if (out_kind == DSP_OUT_FRAMES) {
+                if (active) out[g * ld_out + n] = v;
+            } else if (n < P.lfft) {
+                fr[n] = v;
+            }
+        }
+        if (out_kind == DSP_OUT_FRAMES) continue;  // uniform over the block
+        for (int n = P.lfft + lane; n < P.nfft; n += 64) fr[n] = 0.f;
+        __syncthreads();
+
+        // ---- complex FFT of z[m] = x[2m] + i x[2m+1], m < NFFT/2 ----
+        float2* src = bufA;
+        float2* dst = bufB;
+        int p = 1;
+        for (int s = 0; s < P.n_pass; ++s) {
+            const int R = P.radix[s];
+            if (R == 4) stockham_pass<4>(src, dst, N2, p, lane, P.tw, P.nfft);
+            else if (R == 2) stockham_pass<2>(src, dst, N2, p, lane, P.tw, P.nfft);
+            else stockham_pass<3>(src, dst, N2, p, lane, P.tw, P.nfft);
+            p *= R;
+            float2* tmp = src; src = dst; dst = tmp;
+            __syncthreads();
+        }
+        // ---- untangle to the real-input spectrum, |X|^2 / NFFT (sigproc.py:136-158) ----
+        float* pspec = reinterpret_cast<float*>(dst);  // K = N2 + 1 <= 2*N2 floats
+        const float inv_nfft = 1.0f / (float)P.nfft;
+        float esum = 0.f;
+        for (int k = lane; k <= N2; k += 64) {
+            const float2 zk = src[k == N2 ? 0 : k];
+            const float2 zc = src[k == 0 ? 0 : N2 - k];
+            const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+            const float2 o = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
+            const float2 w = P.tw[k];
+            const float2 x = make_float2(e.x + fmaf(w.x, o.x, -w.y * o.y), e.y + fmaf(w.x, o.y, w.y * o.x));
+            const float m2 = fmaf(x.x, x.x, x.y * x.y);
+            if (out_kind == DSP_OUT_MAGSPEC) {
+                if (active) out[g * ld_out + k] = sqrtf(m2);
+            } else {
+                const float pw = m2 * inv_nfft;
+                if (out_kind == DSP_OUT_POWSPEC) {
+                    if (active) out[g * ld_out + k] = pw;
+                } else {
+                    pspec[k] = pw;
+                    esum += pw;
+                }
+            }
+        }
+        if (out_kind == DSP_OUT_MAGSPEC || out_kind == DSP_OUT_POWSPEC) {
+            __syncthreads();
+            continue;
+        }
+        esum = dsp_wave_sum(esum);
+        if (esum == 0.f) esum = DSP_EPS_F32;  // base.py:26
+        __syncthreads();
+
+        // ---- mel filterbank (base.py:28-30), log (base.py:12) ----
+        float* logmel = reinterpret_cast<float*>(src);  // spectrum Z is dead now
+        for (int j = lane; j < P.M; j += 64) {
+            const int b0 = P.mel_start[j], cnt = P.mel_count[j];
+            const float* w = P.mel_w + P.mel_off[j];
+            float acc = 0.f;
+            for (int i = 0; i < cnt; ++i) acc = fmaf(w[i], pspec[b0 + i], acc);
+            if (acc == 0.f) acc = DSP_EPS_F32;  // base.py:30
+            if (out_kind == DSP_OUT_FBANK) {
+                if (active) out[g * ld_out + j] = acc;
+            } else {
+                logmel[j] = logf(acc);
+            }
+        }
+        if (out_kind == DSP_OUT_FBANK) {
+            if (active && lane == 0) out2[g] = esum;
+            __syncthreads();
+            continue;
+        }
+        __syncthreads();
+        // ---- DCT-II (ortho) * lifter, first C outputs; energy swap (base.py:13-15) ----
+        for (int c = lane; c < P.C; c += 64) {
+            const float* d = P.dct + (size_t)c * P.M;
+            float acc = 0.f;
+            for (int j = 0; j < P.M; ++j) acc = fmaf(d[j], logmel[j], acc);
+            if (c == 0 && P.append_energy) acc = logf(esum);
+            if (active) out[g * ld_out + c] = acc;
+        }
+        __syncthreads();
+    }
+}
+
+// base.delta (base.py:70-79) and, optionally, delta-of-delta in the same pass.
+__global__ __launch_bounds__(256) void delta_kernel(const float* __restrict__ in, int64_t ld_in, BatchGeom bg,
+                                                    int32_t D, int32_t N, float inv_den, float* __restrict__ out,
+                                                    int64_t ld_out, float* __restrict__ out_dd, int64_t ld_dd) {
+    const int64_t total = bg.total_frames * D;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t g = idx / D;
+        const int32_t d = (int32_t)(idx - g * D);
+        int64_t t, T, base;
+        if (bg.uniform_frames > 0) {
+            const int64_t u = g / bg.uniform_frames;
+            base = u * bg.uniform_frames;
+            T = bg.uniform_frames;
+        } else {
+            const int32_t u = dsp_find_utt(bg.frame_off, bg.n_utt, g);
+            base = bg.frame_off[u];
+            T = bg.frame_off[u + 1] - base;
+        }
+        t = g - base;
+        auto x = [&](int64_t tt) -> float {
+            tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
+            return in[(base + tt) * ld_in + d];
+        };
+        auto d1 = [&](int64_t tt) -> float {
+            tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);  // edge-replicated Delta for the second pass
+            float acc = 0.f;
+            for (int n = 1; n <= N; ++n) acc = fmaf((float)n, x(tt + n) - x(tt - n), acc);
+            return acc * inv_den;
+        };
+        out[g * ld_out + d] = d1(t);
+        if (out_dd != nullptr) {
+            float acc = 0.f;
+            for (int n = 1; n <= N; ++n) acc = fmaf((float)n, d1(t + n) - d1(t - n), acc);
+            out_dd[g * ld_dd + d] = acc * inv_den;
+        }
+    }
+}
+
+template <int DTYPE>
+__global__ __launch_bounds__(256) void preemphasis_kernel(const void* __restrict__ wave, const int64_t* __restrict__ off,
+                                                          int32_t n_utt, int64_t total, float coeff,
+                                                          float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t u = dsp_find_utt(off, n_utt, i);
+        float v = dsp_load_sample<DTYPE>(wave, i);
+        if (i > off[u]) v = fmaf(-coeff, dsp_load_sample<DTYPE>(wave, i - 1), v);
+        out[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_columns_kernel(float* __restrict__ x, int64_t rows, int32_t cols,
+                                                            const float* __restrict__ scale) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x)
+        x[i] *= scale[i % cols];
+}
+
+// endpoint.get_amplitude / get_zcr (endpoint.py:109-126,182-198) on rectangular frames
+// (sigproc.to_frames, sigproc.py:11-19).  One wavefront per frame, fp64 accumulation.
+template <int DTYPE>
+__global__ __launch_bounds__(256) void vad_features_kernel(const void* __restrict__ wave, BatchGeom bg, int32_t L,
+                                                           int32_t S, int32_t use_sq, double* __restrict__ amp_sum,
+                                                           int32_t* __restrict__ zcr) {
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t n_tiles = (bg.total_frames + 3) / 4;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t g = tile * 4 + wid;
+        if (g >= bg.total_frames) continue;
+        int32_t utt;
+        int64_t t, s0, nsamp;
+        dsp_locate(bg, g, utt, t, s0, nsamp);
+        const int64_t first = t * (int64_t)S;
+        double acc = 0.0;
+        int32_t cnt = 0;
+        for (int n = lane; n < L; n += 64) {
+            const int64_t pos = first + n;
+            const float a = pos < nsamp ? dsp_load_sample<DTYPE>(wave, s0 + pos) : 0.f;
+            acc += use_sq ? (double)a * (double)a : (double)fabsf(a);
+            if (n + 1 < L) {
+                const float b = pos + 1 < nsamp ? dsp_load_sample<DTYPE>(wave, s0 + pos + 1) : 0.f;
+                cnt += ((a > 0.f && b < 0.f) || (a < 0.f && b > 0.f)) ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            acc += __shfl_xor(acc, o, 64);
+            cnt += __shfl_xor(cnt, o, 64);
+        }
+        if (lane == 0) {
+            amp_sum[g] = acc;
+            zcr[g] = cnt;
+        }
+    }
+}
+
+#define DSP_MAX_SIL 128
+
+// endpoint.amplitude_rule (endpoint.py:133-179, use_acr=False): only the first segment's start and
+// the last segment's end are consumed by basic_endpoint_detection (endpoint.py:43,49).
+__device__ inline void amplitude_rule_dev(const double* __restrict__ amp, int64_t T, double inv_L, double mh,
+                                          double th, int n_l, int n_r, double sigma, double cfg_frame,
+                                          int64_t& left, int64_t& right) {
+    double sil[DSP_MAX_SIL];
+    int ns = 0;
+    const int64_t cl = n_l < T ? n_l : T;                   // amp[:n_l]
+    for (int64_t i = 0; i < cl; ++i) sil[ns++] = amp[i] * inv_L;
+    const int64_t cr = (n_r == 0 || n_r > T) ? T : n_r;     // amp[-n_r:]  (-0 slices the whole list)
+    for (int64_t i = T - cr; i < T; ++i) sil[ns++] = amp[i] * inv_L;
+    for (int i = 1; i < ns; ++i) {                          // insertion sort, ns <= 128
+        double v = sil[i];
+        int j = i - 1;
+        while (j >= 0 && sil[j] > v) { sil[j + 1] = sil[j]; --j; }
+        sil[j + 1] = v;
+    }
+    const int m = ns - 2 > 0 ? ns - 2 : 0;                  // sorted(sil)[:-2]
+    double mean = 0.0, var = 0.0;
+    for (int i = 0; i < m; ++i) mean += sil[i];
+    mean = m > 0 ? mean / m : __longlong_as_double(0x7ff8000000000000LL);
+    for (int i = 0; i < m; ++i) var += (sil[i] - mean) * (sil[i] - mean);
+    const double sd = m > 0 ? sqrt(var / m) : mean;
+    double amax = amp[0] * inv_L;
+    for (int64_t i = 1; i < T; ++i) { double v = amp[i] * inv_L; amax = v > amax ? v : amax; }
+    const double T_H = th / cfg_frame;
+    const double M_L = mean + sigma * sd;
+    const double a = amax * mh;
+    const double M_H = (M_L > a) ? M_L : a;                 // python max(a, M_L): NaN M_L loses
+    bool any = false;
+    int64_t i = 0;
+    while (i < T) {
+        if (amp[i] * inv_L >= M_H) {
+            int64_t j = i, k = i;
+            while (k < T && amp[k] * inv_L > M_H) ++k;
+            if ((double)(k - j) < T_H) {
+                i = k;
+            } else {
+                while (j > 0 && amp[j] * inv_L > M_L) --j;
+                while (k < T && amp[k] * inv_L > M_L) ++k;
+                if (!any) { left = j; any = true; }
+                right = k;
+                i = k;
+            }
+        }
+        ++i;
+    }
+    if (!any) { left = 0; right = T; }
+}
+
+__global__ __launch_bounds__(64) void endpoint_rule_kernel(const double* __restrict__ amp_sum,
+                                                           const int32_t* __restrict__ zcr,
+                                                           const int64_t* __restrict__ frame_off, int32_t n_utt,
+                                                           int32_t L, double cfg_frame, double cfg_step,
+                                                           int32_t* __restrict__ endpoints) {
+    const int32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_utt) return;
+    const int64_t base = frame_off[b];
+    const int64_t T = frame_off[b + 1] - base;
+    const double* amp = amp_sum + base;
+    const int32_t* z = zcr + base;
+    const double inv_L = 1.0 / (double)L;
+    const int n_sil = (int)(0.100 / cfg_step);              // int(l_sil / cfg.step), endpoint.py:151
+    int64_t left = 0, right = T;
+    amplitude_rule_dev(amp, T, inv_L, 0.25, 0.100, n_sil, n_sil, 3.0, cfg_frame, left, right);
+    if (right - left < 50)                                  // endpoint.py:44-45
+        amplitude_rule_dev(amp, T, inv_L, 0.125, 0.100, n_sil, n_sil, 3.0, cfg_frame, left, right);
+    // zcr_rule, endpoint.py:201-220 (l_sil = 0 -> front slice empty; r_sil = 0.1)
+    const double max_shift = 0.400 / cfg_frame;
+    const int64_t cr = (n_sil == 0 || n_sil > T) ? T : n_sil;
+    double mu = 0.0, var = 0.0;
+    for (int64_t i = T - cr; i < T; ++i) mu += (double)z[i];
+    mu /= (double)cr;
+    for (int64_t i = T - cr; i < T; ++i) var += ((double)z[i] - mu) * ((double)z[i] - mu);
+    const double thres = mu + 3.0 * sqrt(var / (double)cr);
+    int64_t j = left;
+    while (j > 0 && (double)(left - j) <= max_shift && (double)z[j] > thres) --j;
+    int64_t k = right;
+    while (k < T && (double)(k - right) <= max_shift && (double)z[k] > thres) ++k;
+    if (k - j < 50) { j = 0; k = T; }                       // endpoint.py:60-62
+    endpoints[2 * b] = (int32_t)j;
+    endpoints[2 * b + 1] = (int32_t)k;
+}

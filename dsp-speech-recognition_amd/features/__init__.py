@@ -1,0 +1,18 @@
+"""MI355X-native drop-in for the reference's ``features`` package (DSP feature front-end).
+
+Put ``dsp-speech-recognition_amd/`` on ``sys.path`` ahead of the reference checkout and
+``from features import mfcc, delta, to_frames`` / ``from features.endpoint import
+basic_endpoint_detection`` (model.py:2,13) resolve here.  Same function names, arguments, defaults
+and return types as features/{sigproc,base,endpoint,preprocess}.py; the arithmetic runs in
+hand-written HIP kernels (gfx950) behind a ctypes C ABI (include/dsp_frontend.h).
+
+Unlike the reference's ``features/__init__.py`` this import has no side effects (no ./log/
+directory, no matplotlib / sklearn import), and the pitch module is out of scope.
+There is no CPU fallback: without the built library or without a GPU every compute call raises.
+"""
+from .base import *  # noqa: F401,F403
+from .sigproc import *  # noqa: F401,F403
+from .endpoint import *  # noqa: F401,F403
+from .preprocess import *  # noqa: F401,F403
+from . import base, sigproc, endpoint, preprocess, batch  # noqa: F401
+from .batch import FeaturePlan, EndpointPlan  # noqa: F401

@@ -1,0 +1,52 @@
+"""The per-utterance glue model.py wraps around the feature path ("next" row f-1 of SURVEY 8f):
+endpoint trim -> unit-variance scaling -> MFCC (with the (1, N) no-pre-emphasis quirk) -> global
+mean removal -> delta(3) / delta-delta(3) -> per-coefficient z-score -> pad to 200 frames.
+
+Round-1 form: composed from the GPU entry points of this package plus O(N) host reductions
+(std of the trimmed clip, mean/std of the [T, 13] matrix).  Citations are file:line of the
+reference's model.py.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .base import delta, mfcc
+from . import endpoint as _endpoint
+
+
+def endpoint_detect(sig, rate):
+    """model.py:52-64 without augmentation: trim to the detected endpoints and divide by the
+    population standard deviation (sklearn ``scale(with_mean=False)``; a zero std divides by 1)."""
+    left, right = _endpoint.basic_endpoint_detection(sig, rate)
+    clip = np.asarray(sig[left:right], dtype=np.float64).reshape(-1, 1)
+    sd = clip.std(axis=0)
+    sd[sd == 0.0] = 1.0
+    return clip / sd
+
+
+def feature_extract_mfcc(sound, rate, nfft=1536):
+    """model.py:66-88 -> ((mfcc0, mfcc1, mfcc2), min(T, 200))."""
+    cfg = _endpoint.cfg
+    m0 = mfcc(np.asarray(sound).reshape(1, -1), rate, winlen=cfg.frame, winstep=cfg.step, nfft=nfft,
+              winfunc=np.hamming)
+    m0 = m0 - np.mean(m0)
+    m1 = delta(m0, 3)
+    m2 = delta(m1, 3)
+    mu, sd = m0.mean(axis=0), m0.std(axis=0)
+    sd[sd == 0.0] = 1.0
+    m0 = (m0 - mu) / sd
+    return (m0, m1, m2), min(len(m0), 200)
+
+
+def pad200(b):
+    """model.py:35-39: zero-pad or truncate a [T, D] stream to exactly 200 frames."""
+    b = np.asarray(b)
+    if len(b) < 200:
+        return np.pad(b, ((0, 200 - len(b)), (0, 0)), 'constant', constant_values=0)
+    return np.array(b[:200])
+
+
+def model_pipeline(sig, rate):
+    """Raw int16 clip -> ((mfcc0, mfcc1, mfcc2), n) exactly as RNNModel.get_batch_full feeds the
+    classifier per utterance (model.py:113-124, augment=False)."""
+    return feature_extract_mfcc(endpoint_detect(sig, rate), rate)

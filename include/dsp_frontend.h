@@ -1,0 +1,170 @@
+/*
+ * dsp_frontend.h -- C ABI of the MI355X-native speech feature front-end (libdsp_frontend.so).
+ *
+ * Drop-in boundary.  The reference (AuCson/DSP-Speech-Recognition) is 100 % Python: its "FFI" for
+ * this path is the module surface of features/{sigproc,base,endpoint}.py.  Each entry point below
+ * names the reference function(s) (file:line, relative to the reference checkout) whose arithmetic
+ * it replaces; the Python mirror in dsp-speech-recognition_amd/features/ binds them with ctypes
+ * under the reference's own function names.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in signatures; `stream` is a hipStream_t passed as void*
+ *     (NULL = default stream); every pointer prefixed d_ is DEVICE memory, h_ is host memory.
+ *   - every function returns DSP_OK (0) or a negative DSP_E* code; dsp_last_error() gives the
+ *     thread-local message.  Nothing falls back to a CPU path: without a GPU calls fail.
+ *   - utterances are concatenated: sample_offsets[B+1] (int64) into the wave buffer,
+ *     frame_offsets[B+1] (int64) into the [sum T_b, D] output (row-major, fp32).
+ *   - no global mutable state besides the thread-local error string; a plan is immutable after
+ *     creation and may be used from several host threads / streams concurrently.
+ */
+#ifndef DSP_FRONTEND_H
+#define DSP_FRONTEND_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSP_ABI_VERSION 1
+
+/* status codes */
+#define DSP_OK          0
+#define DSP_EINVAL     -1   /* bad argument / unsupported configuration */
+#define DSP_EHIP       -2   /* HIP runtime error (message has hipGetErrorString) */
+#define DSP_ENODEV     -3   /* no usable GPU */
+
+/* waveform sample types */
+#define DSP_WAVE_F32    0
+#define DSP_WAVE_I16    1   /* what reader.py:80 yields (int16 PCM) */
+
+/* which stage's output dsp_features_batch writes */
+#define DSP_OUT_FRAMES   0  /* [sumT, L]        sigproc.framesig      sigproc.py:66-98   */
+#define DSP_OUT_MAGSPEC  1  /* [sumT, NFFT/2+1] sigproc.magspec       sigproc.py:136-148 */
+#define DSP_OUT_POWSPEC  2  /* [sumT, NFFT/2+1] sigproc.powspec       sigproc.py:151-158 */
+#define DSP_OUT_FBANK    3  /* [sumT, M] + energy[sumT]  base.fbank   base.py:18-32      */
+#define DSP_OUT_MFCC     4  /* [sumT, C]        base.mfcc             base.py:8-16       */
+
+typedef struct dsp_plan dsp_plan;
+
+/*
+ * Host-built tables for one (rate, L, S, NFFT, M, C, preemph, lifter, window) tuple.  The host side
+ * evaluates everything the reference evaluates in Python/fp64 per call -- round_half_up of the frame
+ * sizes (sigproc.py:55-56,77-78), winfunc(L) (sigproc.py:89), get_filterbanks (base.py:40-58), the
+ * DCT-II/ortho matrix (base.py:13, scipy.fftpack.dct) with the lifter (base.py:60-68) folded in --
+ * once, in fp64, and hands them over rounded to fp32.
+ */
+typedef struct dsp_plan_desc {
+    int32_t frame_len;        /* L  samples per frame (after round_half_up)                        */
+    int32_t frame_step;       /* S  hop in samples                                                 */
+    int32_t nfft;             /* NFFT: 2^k or 3*2^k, 16 <= NFFT <= 4096; frames longer are truncated
+                                 (sigproc.py:143-147)                                              */
+    int32_t nfilt;            /* M  mel filters (0 if the plan is only used up to POWSPEC)         */
+    int32_t numcep;           /* C  cepstra kept, C <= M                                           */
+    int32_t append_energy;    /* base.py:15 -- column 0 := log(frame energy)                       */
+    float   preemph;          /* base.py:22 -- 0 disables the filter                               */
+    const float*   h_window;      /* [L]                                                           */
+    const int32_t* h_mel_start;   /* [M] first FFT bin of filter j with a stored weight            */
+    const int32_t* h_mel_count;   /* [M] number of stored weights                                  */
+    const float*   h_mel_weights; /* [sum count] row after row                                     */
+    const float*   h_dct;         /* [C, M] row-major, lifter already multiplied in                */
+} dsp_plan_desc;
+
+/* ---- library / device plumbing ------------------------------------------------------------- */
+int         dsp_abi_version(void);
+const char* dsp_last_error(void);
+int dsp_device_count(int* n);
+int dsp_set_device(int device);
+int dsp_malloc(void** d_ptr, size_t bytes);
+int dsp_free(void* d_ptr);
+int dsp_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream);
+int dsp_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream);
+int dsp_memset(void* d_dst, int value, size_t bytes, void* stream);
+int dsp_stream_synchronize(void* stream);
+
+/* ---- host-side geometry (no GPU needed) ---------------------------------------------------- */
+/* T = 1 if n <= L else 1 + ceil((n - L) / S)                       sigproc.py:79-82 */
+int dsp_frame_count(int64_t n_samples, int32_t frame_len, int32_t frame_step, int64_t* n_frames);
+/* frame_offsets[0]=0, frame_offsets[b+1]=frame_offsets[b]+T_b      (h_ pointers)    */
+int dsp_frame_offsets(const int64_t* h_sample_offsets, int32_t n_utt, int32_t frame_len,
+                      int32_t frame_step, int64_t* h_frame_offsets);
+
+/* ---- plans --------------------------------------------------------------------------------- */
+int dsp_plan_create(const dsp_plan_desc* desc, dsp_plan** plan);
+int dsp_plan_destroy(dsp_plan* plan);
+
+/* ---- the hot path -------------------------------------------------------------------------- */
+/*
+ * y[0]=x[0]; y[n]=x[n]-coeff*x[n-1] per utterance.        sigproc.preemphasis  sigproc.py:178-185
+ */
+int dsp_preemphasis_batch(const void* d_wave, int wave_dtype, const int64_t* d_sample_offsets,
+                          int32_t n_utt, int64_t n_samples_total, float coeff, float* d_out,
+                          void* stream);
+
+/*
+ * Fused pre-emphasis -> framing*window -> rFFT -> |X|^2/NFFT -> mel -> log -> DCT*lifter -> energy
+ * swap, stopping at `out_kind`.  Replaces sigproc.preemphasis/framesig/magspec/powspec and
+ * base.fbank/mfcc (sigproc.py:66-98,136-158,178-185; base.py:8-32).
+ *   uniform_samples > 0: every utterance has exactly that many samples (offsets may then be NULL).
+ *   d_out2: energy[sumT] for DSP_OUT_FBANK, else ignored (may be NULL).
+ *   ld_out: row stride of d_out in floats (0 = dense).
+ */
+int dsp_features_batch(const dsp_plan* plan, const void* d_wave, int wave_dtype,
+                       const int64_t* d_sample_offsets, const int64_t* d_frame_offsets,
+                       int32_t n_utt, int64_t n_frames_total, int64_t uniform_samples,
+                       int out_kind, float* d_out, int64_t ld_out, float* d_out2, void* stream);
+
+/*
+ * d[t] = sum_{n=-N..N} n * x[clamp(t+n)] / (2 sum i^2), edge-replicated per utterance.
+ *                                                                base.delta  base.py:70-79
+ * Reads columns [0,D) of d_in (row stride ld_in), writes columns [0,D) of d_out (row stride ld_out).
+ * If d_out_dd != NULL also writes delta(delta(x)) there in the same pass (model.py:76-77 pattern).
+ *   uniform_frames > 0: every utterance has exactly that many frames (offsets may be NULL).
+ */
+int dsp_delta_batch(const float* d_in, int64_t ld_in, const int64_t* d_frame_offsets,
+                    int32_t n_utt, int64_t n_frames_total, int64_t uniform_frames, int32_t D,
+                    int32_t N, float* d_out, int64_t ld_out, float* d_out_dd, int64_t ld_out_dd,
+                    void* stream);
+
+/*
+ * BASELINE config 2 in one call: out[sumT, 3C] = mfcc | delta_N | delta_N(delta_N).
+ *                                        base.mfcc + base.delta x2   base.py:8-16,70-79
+ */
+int dsp_mfcc_delta_batch(const dsp_plan* plan, const void* d_wave, int wave_dtype,
+                         const int64_t* d_sample_offsets, const int64_t* d_frame_offsets,
+                         int32_t n_utt, int64_t n_frames_total, int64_t uniform_samples,
+                         int32_t delta_n, float* d_out, void* stream);
+
+/* c[:, n] *= lift[n]                                           base.lifter  base.py:60-68 */
+int dsp_scale_columns(float* d_x, int64_t rows, int32_t cols, const float* d_scale, void* stream);
+
+/* ---- endpointing (energy / ZCR) ------------------------------------------------------------ */
+/*
+ * Per frame of length L / hop S (rectangular window, sizes truncated by the caller as
+ * sigproc.to_frames does, sigproc.py:11-19):
+ *   amp_sum[t] = sum |x| (or sum x^2)   -> endpoint.get_amplitude = amp_sum / L   endpoint.py:109-126
+ *   zcr[t]     = #{ i : x[i]*x[i+1] < 0 }, sign-pair test                         endpoint.py:182-198
+ * fp64 accumulation; exact for int16 input.
+ */
+int dsp_vad_features_batch(const void* d_wave, int wave_dtype, const int64_t* d_sample_offsets,
+                           const int64_t* d_frame_offsets, int32_t n_utt, int64_t n_frames_total,
+                           int64_t uniform_samples, int32_t frame_len, int32_t frame_step,
+                           int32_t use_sq, double* d_amp_sum, int32_t* d_zcr, void* stream);
+
+/*
+ * The two-threshold state machine, one utterance per thread, fp64 thresholds:
+ * endpoint.amplitude_rule (endpoint.py:133-179, use_acr=False), the mh=0.125 retry and the
+ * <50-frame fallbacks of endpoint.basic_endpoint_detection (endpoint.py:42-62), endpoint.zcr_rule
+ * (endpoint.py:201-220).  cfg_frame/cfg_step are the reference's cfg.frame / cfg.step.
+ * Writes frame indices (left2,right2) per utterance to d_endpoints[2*b .. 2*b+1]; the caller maps
+ * them to samples with int(left*cfg.step*rate) in fp64 (endpoint.py:64).
+ */
+int dsp_endpoint_rule_batch(const double* d_amp_sum, const int32_t* d_zcr,
+                            const int64_t* d_frame_offsets, int32_t n_utt, int32_t frame_len,
+                            double cfg_frame, double cfg_step, int32_t* d_endpoints, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSP_FRONTEND_H */
