@@ -306,7 +306,7 @@ int dsp_features_batch(const dsp_plan* plan, const void* d_wave, int wave_dtype,
     if (uniform_samples > 0 && bg.uniform_frames * n_utt != n_frames_total)
         return fail(DSP_EINVAL, "n_frames_total %lld != n_utt*T (%d*%lld)", (long long)n_frames_total, n_utt, (long long)bg.uniform_frames);
     hipStream_t st = (hipStream_t)stream;
-    if (out_kind == DSP_OUT_MFCC && fast512_applicable(plan))
+    if (out_kind == DSP_OUT_MFCC && fast512_applicable(plan, bg, d_wave, wave_dtype))
         return fast512_launch(plan, d_wave, wave_dtype, bg, d_out, ld_out, st);
     return launch_generic(plan, d_wave, wave_dtype, bg, out_kind, d_out, ld_out, d_out2, st);
 }

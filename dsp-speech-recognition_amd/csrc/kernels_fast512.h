@@ -1,14 +1,450 @@
-// Specialised NFFT=512 MFCC kernel (placeholder until the register-resident FFT lands).
+// Specialised fused MFCC kernel for NFFT = 512 (the BASELINE metric configuration and every other
+// plan with L <= 512): waveform -> MFCC without touching HBM in between.
+//
+// Work decomposition (gfx950, wave64):
+//   * one wavefront = 8 consecutive frames of one utterance, 8 lanes per frame (lane = 8 f + c);
+//   * the 512-point real FFT of a frame is split n = 16 n1 + n2:
+//       pass 1  lane c owns columns n2 = 2c, 2c+1: ONE in-register complex FFT32 over n1 of
+//               col_a + i col_b, untangled to rows k1 = 0..16 (real-input symmetry), twiddled;
+//       exchange through LDS (2 x 1 KB per frame, XOR-swizzled, conflict-free b128 both ways);
+//       pass 2  lane c owns rows k1 = c and c + 8: TWO in-register complex FFT16 over n2
+//               -> X[k1 + 32 k2]; rows 0 and 16 (both real) ride together as one packed 32-point
+//               real FFT in lane 0's first slot, so every lane runs the same two FFT16s;
+//   * |X|^2 -> LDS (one 264-float row per frame) -> table-driven sparse mel triangles (lane c owns
+//     filters c, c+8, ...) -> log -> DCT*lifter partial sums -> 3-step DPP all-reduce over the
+//     frame's 8 lanes -> energy swap -> store.
+//   * the 8 frames' samples (7 S + L of them) are read from HBM once, coalesced 16 B per lane,
+//     pre-emphasised on the fly and staged in LDS; overlapping frames re-read LDS, not HBM.
+// No MFMA: the path has no dense contraction (mel is 96 % sparse, the DCT is 13 x 40).
 #pragma once
 
-#include "dsp_common.h"
+#include <cmath>
+#include <vector>
 
-static inline int fast512_plan_init(dsp_plan* p, const dsp_plan_desc*, const int32_t*) {
+#include "dsp_common.h"
+#include "fft_inreg.h"
+
+#define F512_WAVE_FLOATS 2112  // per-wave LDS: 8 frames x 264 floats (staging / exchange alias it)
+#define F512_PS_STRIDE 264     // == 8 (mod 32): the 8 frames' rows start on distinct bank octets
+#define F512_MAX_NI 8
+
+struct F512Params {
+    const float* tables;   // device blob copied to LDS by every workgroup
+    int32_t tab_floats;    // multiple of 64 floats (256 B)
+    int32_t off_tw1, off_dct, off_prog;
+    int32_t L, S, M, C, append_energy;
+    float preemph;
+    int32_t span_vec;      // ceil((7 S + L) / 4): 16-byte vectors staged per wave
+    int32_t len[F512_MAX_NI];
+    int64_t groups_per_utt, total_groups;
+};
+
+struct Fast512Plan {
+    float* d_tables;
+    F512Params P;
+    int variant;           // which <NROWS, NI, NC> instantiation serves this plan
+};
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// Sum over the 8 lanes of a frame (lanes 8f .. 8f+7); every lane ends with the total.
+__device__ __forceinline__ float frame_allreduce(float v) {
+    v += dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);  // row_half_mirror: lane i <-> 7 - i inside each 8-lane half row
+    return v;
+}
+
+#define F512_FENCE() asm volatile("" ::: "memory")
+
+template <int DTYPE>
+__device__ __forceinline__ void f512_load4(const void* __restrict__ wave, int64_t idx, int64_t remain, float (&x)[4]) {
+    // x[e] = sample idx + e for e < remain (remain may be <= 0 or >= 4), else 0
+    if (remain >= 4) {
+        if constexpr (DTYPE == DSP_WAVE_I16) {
+            const short4 v = *reinterpret_cast<const short4*>(reinterpret_cast<const int16_t*>(wave) + idx);
+            x[0] = (float)v.x; x[1] = (float)v.y; x[2] = (float)v.z; x[3] = (float)v.w;
+        } else {
+            const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(wave) + idx);
+            x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = e < remain ? dsp_load_sample<DTYPE>(wave, idx + e) : 0.f;
+    }
+}
+
+template <int NROWS, int NI, int NC, int DTYPE, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void mfcc512_kernel(F512Params P, BatchGeom bg,
+                                                             const void* __restrict__ wave,
+                                                             float* __restrict__ out, int64_t ld_out) {
+    extern __shared__ __attribute__((aligned(256))) float smem_f[];
+    float* const smem = smem_f;
+    const int tid = threadIdx.x;
+    for (int i = tid * 4; i < P.tab_floats; i += 64 * WAVES * 4)
+        *reinterpret_cast<float4*>(smem + i) = *reinterpret_cast<const float4*>(P.tables + i);
+    __syncthreads();
+    const float* s_win = smem;
+    const float4* s_tw1 = reinterpret_cast<const float4*>(smem + P.off_tw1);
+    const float* s_dct = smem + P.off_dct;
+    const float2* s_prog = reinterpret_cast<const float2*>(smem + P.off_prog);
+
+    const int wid = tid >> 6, lane = tid & 63;
+    const int f = lane >> 3, c = lane & 7;
+    float* wbuf = smem + P.tab_floats + wid * F512_WAVE_FLOATS;
+    const int sigma_hi = ((f >> 1) & 1) << 2;  // exchange swizzle: slot ^= (u >> 1) ^ sigma_hi
+    const int T = (int)bg.uniform_frames;
+    const int64_t nsamp = bg.uniform_samples;
+
+    for (int64_t G = (int64_t)blockIdx.x * WAVES + wid; G < P.total_groups; G += (int64_t)gridDim.x * WAVES) {
+        const int64_t utt = G / P.groups_per_utt;
+        const int t0 = (int)(G - utt * P.groups_per_utt) * 8;
+        const int64_t s0 = utt * nsamp;
+        const int64_t base = (int64_t)t0 * P.S;
+
+        // ---- stage 7 S + L samples: coalesced 16 B loads, pre-emphasis, zero fill past the end ----
+        for (int v = lane; v < P.span_vec; v += 64) {
+            const int64_t pos = base + 4 * v;
+            float x[4];
+            f512_load4<DTYPE>(wave, s0 + pos, nsamp - pos, x);
+            const float prev = (pos > 0 && pos <= nsamp) ? dsp_load_sample<DTYPE>(wave, s0 + pos - 1) : 0.f;
+            float4 y;
+            y.x = fmaf(-P.preemph, prev, x[0]);
+            y.y = fmaf(-P.preemph, x[0], x[1]);
+            y.z = fmaf(-P.preemph, x[1], x[2]);
+            y.w = fmaf(-P.preemph, x[2], x[3]);
+            if (pos + 3 >= nsamp) {  // the reference pads with zeros AFTER pre-emphasis
+                if (pos + 0 >= nsamp) y.x = 0.f;
+                if (pos + 1 >= nsamp) y.y = 0.f;
+                if (pos + 2 >= nsamp) y.z = 0.f;
+                y.w = 0.f;
+            }
+            *reinterpret_cast<float4*>(wbuf + 4 * v) = y;
+        }
+        F512_FENCE();
+
+        // ---- pass 1: window, complex FFT32 over n1 of (column 2c) + i (column 2c+1) ----
+        cpx z[32];
+        {
+            const float* fr = wbuf + f * P.S + 2 * c;
+            const float* wn = s_win + 2 * c;
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1) {
+                if (n1 < NROWS) {
+                    const float2 xv = *reinterpret_cast<const float2*>(fr + 16 * n1);
+                    const float2 wv = *reinterpret_cast<const float2*>(wn + 16 * n1);
+                    z[n1] = {xv.x * wv.x, xv.y * wv.y};
+                } else {
+                    z[n1] = {0.f, 0.f};
+                }
+            }
+        }
+        FFTReg<32>::template run<NROWS>(z);
+        F512_FENCE();
+
+        // untangle the two real columns (rows k1 = 0..16, factor 2 kept) and twiddle by W512^(n2 k1)
+        cpx ra[16], rb[16];  // index k1 = 1..15 used
+#pragma unroll
+        for (int k1 = 1; k1 < 16; ++k1) {
+            const cpx zk = z[k1], zm = z[32 - k1];
+            const cpx a = {zk.x + zm.x, zk.y - zm.y};
+            const cpx b = {zk.y + zm.y, zm.x - zk.x};
+            const float4 t = s_tw1[(k1 - 1) * 8 + c];
+            ra[k1] = cmulc(a, t.x, t.y);
+            rb[k1] = cmulc(b, t.z, t.w);
+        }
+        const float qa = 2.f * z[0].x, qb = 2.f * z[0].y, pa = 2.f * z[16].x, pb = 2.f * z[16].y;
+
+        // ---- exchange round A: units 0..7 (unit 0 = packed rows 0/16, units 1..7 = rows 1..7) ----
+        float* xb = wbuf + f * 256;
+        cpx u0[16], u1[16];
+        {
+            const int s0x = sigma_hi;  // unit 0: (0 >> 1) ^ sigma_hi
+            *reinterpret_cast<float2*>(xb + 4 * ((c >> 1) ^ s0x) + 2 * (c & 1)) = make_float2(qa + pa, qb + pb);
+            *reinterpret_cast<float2*>(xb + 4 * ((4 + (c >> 1)) ^ s0x) + 2 * (c & 1)) = make_float2(qa - pa, qb - pb);
+#pragma unroll
+            for (int k1 = 1; k1 < 8; ++k1) {
+                const int sg = (k1 >> 1) ^ sigma_hi;
+                *reinterpret_cast<float4*>(xb + k1 * 32 + 4 * (c ^ sg)) = make_float4(ra[k1].x, ra[k1].y, rb[k1].x, rb[k1].y);
+            }
+            F512_FENCE();
+            const int sg = (c >> 1) ^ sigma_hi;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float4 t = *reinterpret_cast<const float4*>(xb + c * 32 + 4 * (i ^ sg));
+                u0[2 * i] = {t.x, t.y};
+                u0[2 * i + 1] = {t.z, t.w};
+            }
+            F512_FENCE();
+            // ---- round B: units 8..15 = rows 8..15 (slot u - 8) ----
+#pragma unroll
+            for (int k1 = 8; k1 < 16; ++k1) {
+                const int u = k1 - 8;
+                const int sw = (u >> 1) ^ sigma_hi;
+                *reinterpret_cast<float4*>(xb + u * 32 + 4 * (c ^ sw)) = make_float4(ra[k1].x, ra[k1].y, rb[k1].x, rb[k1].y);
+            }
+            F512_FENCE();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float4 t = *reinterpret_cast<const float4*>(xb + c * 32 + 4 * (i ^ sg));
+                u1[2 * i] = {t.x, t.y};
+                u1[2 * i + 1] = {t.z, t.w};
+            }
+            F512_FENCE();
+        }
+
+        // ---- pass 2: two complex FFT16 over n2 ----
+        FFTReg<16>::run(u0);
+        FFTReg<16>::run(u1);
+
+        // power spectrum |X|^2 / 512 (rows carry a factor 2 -> 1/2048)
+        float p0[16], p1[16], p256 = 0.f;
+        constexpr float S1 = 1.0f / 2048.0f, S2 = 1.0f / 32768.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            p0[k] = S1 * fmaf(u0[k].x, u0[k].x, u0[k].y * u0[k].y);
+            p1[k] = S1 * fmaf(u1[k].x, u1[k].x, u1[k].y * u1[k].y);
+        }
+        if (c == 0) {
+            // lane 0, slot 0: u0 = FFT16 of r[2m] + i r[2m+1]; finish the 32-point real FFT:
+            // bins 16 j, j = 0..16 (factor 8 carried -> 1/32768)
+            const float e0 = u0[0].x + u0[0].y, e16 = u0[0].x - u0[0].y;
+            p0[0] = S2 * 4.f * e0 * e0;
+            p256 = S2 * 4.f * e16 * e16;
+            p0[8] = S2 * 4.f * fmaf(u0[8].x, u0[8].x, u0[8].y * u0[8].y);
+#pragma unroll
+            for (int j = 1; j < 8; ++j) {
+                const cpx zj = u0[j], zq = u0[16 - j];
+                const cpx e = {zj.x + zq.x, zj.y - zq.y};
+                const cpx d = {zj.x - zq.x, zj.y + zq.y};
+                const cpx o = {d.y, -d.x};
+                const cpx tw = cmulc(o, DSP_COS32[j], -DSP_SIN32[j]);  // W32^j * o
+                const cpx rp = {e.x + tw.x, e.y + tw.y};
+                const cpx rm = {e.x - tw.x, e.y - tw.y};
+                p0[j] = S2 * fmaf(rp.x, rp.x, rp.y * rp.y);
+                p0[16 - j] = S2 * fmaf(rm.x, rm.x, rm.y * rm.y);
+            }
+        }
+        float energy = p256;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) energy += p0[k] + p1[k];
+        energy = frame_allreduce(energy);
+        if (energy == 0.f) energy = DSP_EPS_F32;
+
+        // ---- power spectrum -> LDS row of this frame ----
+        float* ps = wbuf + f * F512_PS_STRIDE;
+        {
+            const int lo0 = c, st0 = c ? 32 : 16, hi0 = c ? 512 - c : 0, sh0 = c ? -32 : 16;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                ps[k < 8 ? lo0 + st0 * k : hi0 + sh0 * k] = p0[k];
+                ps[k < 8 ? (c + 8) + 32 * k : 512 - 32 * k - (c + 8)] = p1[k];
+            }
+            if (c == 0) ps[256] = p256;
+        }
+        F512_FENCE();
+
+        // ---- sparse mel triangles (table driven), log ----
+        float lm[NI];
+        {
+            const float2* pg = s_prog + c;
+            const char* psb = reinterpret_cast<const char*>(ps);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                float acc = 0.f;
+                const int n = P.len[i];
+                for (int s = 0; s < n; ++s) {
+                    const float2 e = *pg;
+                    pg += 8;
+                    acc = fmaf(e.x, *reinterpret_cast<const float*>(psb + __float_as_int(e.y)), acc);
+                }
+                if (acc == 0.f) acc = DSP_EPS_F32;
+                lm[i] = __logf(acc);
+            }
+        }
+        F512_FENCE();
+
+        // ---- DCT-II * lifter partial sums over this lane's filters, all-reduce over the frame ----
+        float cep[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) cep[k] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const float4* dr = reinterpret_cast<const float4*>(s_dct + (i * 8 + c) * 16);
+#pragma unroll
+            for (int q = 0; q < (NC + 3) / 4; ++q) {
+                const float4 d = dr[q];
+                if (4 * q + 0 < NC) cep[4 * q + 0] = fmaf(d.x, lm[i], cep[4 * q + 0]);
+                if (4 * q + 1 < NC) cep[4 * q + 1] = fmaf(d.y, lm[i], cep[4 * q + 1]);
+                if (4 * q + 2 < NC) cep[4 * q + 2] = fmaf(d.z, lm[i], cep[4 * q + 2]);
+                if (4 * q + 3 < NC) cep[4 * q + 3] = fmaf(d.w, lm[i], cep[4 * q + 3]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NC; ++k) cep[k] = frame_allreduce(cep[k]);
+        if (P.append_energy) cep[0] = __logf(energy);
+
+        // ---- store: lane c writes coefficients c and c + 8 of its frame ----
+        float v0 = cep[0], v1 = NC > 8 ? cep[8] : 0.f;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            if (k < NC && c == k) v0 = cep[k];
+            if (k + 8 < NC && c == k) v1 = cep[k + 8];
+        }
+        const int t = t0 + f;
+        if (t < T) {
+            float* o = out + (utt * T + t) * ld_out;
+            if (c < P.C) o[c] = v0;
+            if (c + 8 < P.C) o[c + 8] = v1;
+        }
+        F512_FENCE();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static inline bool fast512_shape_ok(const dsp_plan_desc* d) {
+    return d->nfft == 512 && d->frame_len <= 512 && (d->frame_step % 2) == 0 && d->frame_step >= 2 &&
+           7 * d->frame_step + 512 + 16 <= F512_WAVE_FLOATS && d->nfilt >= 1 &&
+           d->nfilt <= 8 * F512_MAX_NI && d->numcep >= 1 && d->numcep <= 16;
+}
+
+static inline int fast512_plan_init(dsp_plan* p, const dsp_plan_desc* d, const int32_t* mel_off) {
     p->d_fast = nullptr;
+    if (!fast512_shape_ok(d)) return DSP_OK;
+    const int M = d->nfilt, C = d->numcep, L = d->frame_len;
+    const int ni_real = (M + 7) / 8, nrows = (L + 15) / 16;
+    int variant, NI;  // template instantiation: <NROWS, NI, NC>
+    if (nrows <= 25 && ni_real <= 4 && C <= 13) { variant = 0; NI = 4; }
+    else if (nrows <= 25 && ni_real <= 5 && C <= 13) { variant = 1; NI = 5; }
+    else { variant = 2; NI = F512_MAX_NI; }
+    std::vector<float> win(512, 0.f);
+    for (int n = 0; n < L; ++n) win[n] = d->h_window[n];
+    std::vector<float> tw1(15 * 8 * 4);
+    for (int k1 = 1; k1 < 16; ++k1)
+        for (int c = 0; c < 8; ++c)
+            for (int h = 0; h < 2; ++h) {
+                const double a = -2.0 * M_PI * (double)((2 * c + h) * k1) / 512.0;
+                tw1[((k1 - 1) * 8 + c) * 4 + 2 * h] = (float)cos(a);
+                tw1[((k1 - 1) * 8 + c) * 4 + 2 * h + 1] = (float)sin(a);
+            }
+    std::vector<float> dct((size_t)NI * 8 * 16, 0.f);
+    for (int i = 0; i < NI; ++i)
+        for (int c = 0; c < 8; ++c) {
+            const int j = c + 8 * i;
+            if (j >= M) continue;
+            for (int k = 0; k < C; ++k) dct[((size_t)i * 8 + c) * 16 + k] = d->h_dct[(size_t)k * M + j];
+        }
+    Fast512Plan* fp = new Fast512Plan();
+    memset(fp, 0, sizeof(*fp));
+    std::vector<float> prog;
+    int n_steps = 0;
+    for (int i = 0; i < NI; ++i) {
+        int len = 0;
+        for (int c = 0; c < 8; ++c) {
+            const int j = c + 8 * i;
+            if (j < M && d->h_mel_count[j] > len) len = d->h_mel_count[j];
+        }
+        fp->P.len[i] = len;
+        for (int s = 0; s < len; ++s)
+            for (int c = 0; c < 8; ++c) {
+                const int j = c + 8 * i;
+                float w = 0.f;
+                int32_t off = 0;
+                if (j < M && s < d->h_mel_count[j]) {
+                    w = d->h_mel_weights[mel_off[j] + s];
+                    off = 4 * (d->h_mel_start[j] + s);
+                }
+                float offf;
+                memcpy(&offf, &off, 4);
+                prog.push_back(w);
+                prog.push_back(offf);
+            }
+        n_steps += len;
+    }
+    auto pad64 = [](size_t n) { return (n + 63) / 64 * 64; };
+    const size_t o_tw1 = 512, o_dct = o_tw1 + tw1.size(), o_prog = pad64(o_dct + dct.size());
+    const size_t total = pad64(o_prog + prog.size());
+    std::vector<float> blob(total, 0.f);
+    memcpy(blob.data(), win.data(), 512 * 4);
+    memcpy(blob.data() + o_tw1, tw1.data(), tw1.size() * 4);
+    memcpy(blob.data() + o_dct, dct.data(), dct.size() * 4);
+    if (!prog.empty()) memcpy(blob.data() + o_prog, prog.data(), prog.size() * 4);
+    if (hipMalloc(reinterpret_cast<void**>(&fp->d_tables), total * 4) != hipSuccess ||
+        hipMemcpy(fp->d_tables, blob.data(), total * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        delete fp;
+        return DSP_EHIP;
+    }
+    fp->P.tables = fp->d_tables;
+    fp->P.tab_floats = (int32_t)total;
+    fp->P.off_tw1 = (int32_t)o_tw1; fp->P.off_dct = (int32_t)o_dct; fp->P.off_prog = (int32_t)o_prog;
+    fp->P.L = L; fp->P.S = d->frame_step; fp->P.M = M; fp->P.C = C;
+    fp->P.append_energy = d->append_energy ? 1 : 0;
+    fp->P.preemph = d->preemph;
+    fp->P.span_vec = (7 * d->frame_step + L + 3) / 4;
+    fp->variant = variant;
+    p->d_fast = fp;
     return DSP_OK;
 }
-static inline void fast512_plan_free(dsp_plan*) {}
-static inline bool fast512_applicable(const dsp_plan*) { return false; }
-static inline int fast512_launch(const dsp_plan*, const void*, int, const BatchGeom&, float*, int64_t, hipStream_t) {
-    return DSP_EINVAL;
+
+static inline void fast512_plan_free(dsp_plan* p) {
+    Fast512Plan* fp = static_cast<Fast512Plan*>(p->d_fast);
+    if (!fp) return;
+    (void)hipFree(fp->d_tables);
+    delete fp;
+    p->d_fast = nullptr;
+}
+
+// uniform batches whose utterances start 16-byte aligned (int16: 8-byte) take the fast path
+static inline bool fast512_applicable(const dsp_plan* p, const BatchGeom& bg, const void* d_wave, int dtype) {
+    if (!p->d_fast) return false;
+    if (bg.uniform_samples <= 0 || (bg.uniform_samples % 4) != 0) return false;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(d_wave);
+    return (a % (dtype == DSP_WAVE_I16 ? 8 : 16)) == 0;
+}
+
+#define F512_WAVES 8
+
+template <int NROWS, int NI, int NC>
+static int fast512_launch_t(const Fast512Plan* fp, const F512Params& P, const void* d_wave, int dtype,
+                            const BatchGeom& bg, float* d_out, int64_t ld_out, hipStream_t st) {
+    const size_t lds = ((size_t)P.tab_floats + (size_t)F512_WAVES * F512_WAVE_FLOATS) * sizeof(float);
+    int64_t blocks = (P.total_groups + F512_WAVES - 1) / F512_WAVES;
+    if (blocks > 512) blocks = 512;  // 256 CUs x 2 resident workgroups; waves grid-stride beyond
+    hipError_t e;
+    if (dtype == DSP_WAVE_I16) {
+        auto k = mfcc512_kernel<NROWS, NI, NC, DSP_WAVE_I16, F512_WAVES>;
+        static size_t lds_set = 0;  // raise the dynamic-LDS limit once per instantiation (and on growth)
+        if (lds > lds_set) {
+            e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return DSP_EHIP;
+            lds_set = lds;
+        }
+        k<<<(int)blocks, 64 * F512_WAVES, lds, st>>>(P, bg, d_wave, d_out, ld_out);
+    } else {
+        auto k = mfcc512_kernel<NROWS, NI, NC, DSP_WAVE_F32, F512_WAVES>;
+        static size_t lds_set = 0;
+        if (lds > lds_set) {
+            e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return DSP_EHIP;
+            lds_set = lds;
+        }
+        k<<<(int)blocks, 64 * F512_WAVES, lds, st>>>(P, bg, d_wave, d_out, ld_out);
+    }
+    return hipGetLastError() == hipSuccess ? DSP_OK : DSP_EHIP;
+}
+
+static inline int fast512_launch(const dsp_plan* p, const void* d_wave, int dtype, const BatchGeom& bg,
+                                 float* d_out, int64_t ld_out, hipStream_t st) {
+    const Fast512Plan* fp = static_cast<const Fast512Plan*>(p->d_fast);
+    F512Params P = fp->P;
+    P.groups_per_utt = (bg.uniform_frames + 7) / 8;
+    P.total_groups = P.groups_per_utt * bg.n_utt;
+    // exact instantiations for the common shapes, a padded catch-all otherwise (chosen at plan init)
+    if (fp->variant == 0) return fast512_launch_t<25, 4, 13>(fp, P, d_wave, dtype, bg, d_out, ld_out, st);
+    if (fp->variant == 1) return fast512_launch_t<25, 5, 13>(fp, P, d_wave, dtype, bg, d_out, ld_out, st);
+    return fast512_launch_t<32, 8, 16>(fp, P, d_wave, dtype, bg, d_out, ld_out, st);
 }
