@@ -330,8 +330,18 @@ int dsp_delta_batch(const float* d_in, int64_t ld_in, const int64_t* d_frame_off
     int den = 0;
     for (int i = 1; i <= N; ++i) den += i * i;
     const float inv_den = (float)(1.0 / (2.0 * den));
-    delta_kernel<<<grid_for(n_frames_total * D, 256), 256, 0, (hipStream_t)stream>>>(
-        d_in, ld_in, bg, D, N, inv_den, d_out, ld_out, d_out_dd, ld_out_dd);
+    // tiled LDS kernel for uniform batches (tile table is arithmetic); per-element kernel otherwise
+    const size_t lds = ((size_t)(DT_TILE + 4 * N) + (size_t)(DT_TILE + 2 * N)) * D * sizeof(float);
+    if (uniform_frames > 0 && lds <= 64 * 1024) {
+        const int64_t tiles = (uniform_frames + DT_TILE - 1) / DT_TILE;
+        const int64_t blocks = tiles * n_utt;
+        if (blocks > 0x7fffffff) return fail(DSP_EINVAL, "too many delta tiles");
+        delta_tiled_kernel<<<(int)blocks, 256, lds, (hipStream_t)stream>>>(
+            d_in, ld_in, bg, D, N, inv_den, d_out, ld_out, d_out_dd, ld_out_dd, (int32_t)tiles, nullptr);
+    } else {
+        delta_kernel<<<grid_for(n_frames_total * D, 256), 256, 0, (hipStream_t)stream>>>(
+            d_in, ld_in, bg, D, N, inv_den, d_out, ld_out, d_out_dd, ld_out_dd);
+    }
     HIP_TRY(hipGetLastError());
     return DSP_OK;
 }

@@ -27,15 +27,22 @@
 #define F512_WAVE_FLOATS 2112  // per-wave LDS: 8 frames x 264 floats (staging / exchange alias it)
 #define F512_PS_STRIDE 264     // == 8 (mod 32): the 8 frames' rows start on distinct bank octets
 #define F512_MAX_NI 8
+#ifndef F512_WAVES
+#define F512_WAVES 8
+#endif
+#ifndef F512_MIN_WAVES_PER_SIMD
+#define F512_MIN_WAVES_PER_SIMD 2
+#endif
 
 struct F512Params {
     const float* tables;   // device blob copied to LDS by every workgroup
     int32_t tab_floats;    // multiple of 64 floats (256 B)
-    int32_t off_tw1, off_dct, off_prog;
+    int32_t off_tw1, off_dct, off_melw, off_mels;
+    int32_t melw_row;      // floats per lane row of mel weights (multiple of 4, /4 odd: conflict-free b128)
     int32_t L, S, M, C, append_energy;
     float preemph;
     int32_t span_vec;      // ceil((7 S + L) / 4): 16-byte vectors staged per wave
-    int32_t len[F512_MAX_NI];
+    int32_t len[F512_MAX_NI];  // padded (multiple of 8) taps per filter group
     int64_t groups_per_utt, total_groups;
 };
 
@@ -60,24 +67,18 @@ __device__ __forceinline__ float frame_allreduce(float v) {
 #define F512_FENCE() asm volatile("" ::: "memory")
 
 template <int DTYPE>
-__device__ __forceinline__ void f512_load4(const void* __restrict__ wave, int64_t idx, int64_t remain, float (&x)[4]) {
-    // x[e] = sample idx + e for e < remain (remain may be <= 0 or >= 4), else 0
-    if (remain >= 4) {
-        if constexpr (DTYPE == DSP_WAVE_I16) {
-            const short4 v = *reinterpret_cast<const short4*>(reinterpret_cast<const int16_t*>(wave) + idx);
-            x[0] = (float)v.x; x[1] = (float)v.y; x[2] = (float)v.z; x[3] = (float)v.w;
-        } else {
-            const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(wave) + idx);
-            x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
-        }
+__device__ __forceinline__ void f512_load4(const void* __restrict__ wave, int64_t idx, float (&x)[4]) {
+    if constexpr (DTYPE == DSP_WAVE_I16) {
+        const short4 v = *reinterpret_cast<const short4*>(reinterpret_cast<const int16_t*>(wave) + idx);
+        x[0] = (float)v.x; x[1] = (float)v.y; x[2] = (float)v.z; x[3] = (float)v.w;
     } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) x[e] = e < remain ? dsp_load_sample<DTYPE>(wave, idx + e) : 0.f;
+        const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(wave) + idx);
+        x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
     }
 }
 
-template <int NROWS, int NI, int NC, int DTYPE, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void mfcc512_kernel(F512Params P, BatchGeom bg,
+template <int NROWS, int NI, int NC, int NSTAGE, int DTYPE, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_kernel(F512Params P, BatchGeom bg,
                                                              const void* __restrict__ wave,
                                                              float* __restrict__ out, int64_t ld_out) {
     extern __shared__ __attribute__((aligned(256))) float smem_f[];
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(64 * WAVES) void mfcc512_kernel(F512Params P, Batch
     const float* s_win = smem;
     const float4* s_tw1 = reinterpret_cast<const float4*>(smem + P.off_tw1);
     const float* s_dct = smem + P.off_dct;
-    const float2* s_prog = reinterpret_cast<const float2*>(smem + P.off_prog);
+    const float* s_melw = smem + P.off_melw;
 
     const int wid = tid >> 6, lane = tid & 63;
     const int f = lane >> 3, c = lane & 7;
@@ -97,6 +98,9 @@ __global__ __launch_bounds__(64 * WAVES) void mfcc512_kernel(F512Params P, Batch
     const int sigma_hi = ((f >> 1) & 1) << 2;  // exchange swizzle: slot ^= (u >> 1) ^ sigma_hi
     const int T = (int)bg.uniform_frames;
     const int64_t nsamp = bg.uniform_samples;
+    int mel_start[NI];  // first FFT bin of this lane's filter in group i (kept in registers)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) mel_start[i] = __float_as_int(smem[P.off_mels + i * 8 + (tid & 7)]);
 
     for (int64_t G = (int64_t)blockIdx.x * WAVES + wid; G < P.total_groups; G += (int64_t)gridDim.x * WAVES) {
         const int64_t utt = G / P.groups_per_utt;
@@ -104,24 +108,32 @@ __global__ __launch_bounds__(64 * WAVES) void mfcc512_kernel(F512Params P, Batch
         const int64_t s0 = utt * nsamp;
         const int64_t base = (int64_t)t0 * P.S;
 
-        // ---- stage 7 S + L samples: coalesced 16 B loads, pre-emphasis, zero fill past the end ----
-        for (int v = lane; v < P.span_vec; v += 64) {
-            const int64_t pos = base + 4 * v;
-            float x[4];
-            f512_load4<DTYPE>(wave, s0 + pos, nsamp - pos, x);
-            const float prev = (pos > 0 && pos <= nsamp) ? dsp_load_sample<DTYPE>(wave, s0 + pos - 1) : 0.f;
-            float4 y;
-            y.x = fmaf(-P.preemph, prev, x[0]);
-            y.y = fmaf(-P.preemph, x[0], x[1]);
-            y.z = fmaf(-P.preemph, x[1], x[2]);
-            y.w = fmaf(-P.preemph, x[2], x[3]);
-            if (pos + 3 >= nsamp) {  // the reference pads with zeros AFTER pre-emphasis
-                if (pos + 0 >= nsamp) y.x = 0.f;
-                if (pos + 1 >= nsamp) y.y = 0.f;
-                if (pos + 2 >= nsamp) y.z = 0.f;
-                y.w = 0.f;
+        // ---- stage 7 S + L samples: coalesced 16 B loads (all issued before the first use),
+        //      pre-emphasis, zero fill past the end.  pos and nsamp are multiples of 4, so a 16-byte
+        //      vector is either entirely inside the utterance or entirely padding. ----
+        {
+            float xs[NSTAGE][4], prevs[NSTAGE];
+#pragma unroll
+            for (int r = 0; r < NSTAGE; ++r) {
+                const int v = lane + 64 * r;
+                const int64_t pos = base + 4 * v;
+                const bool valid = v < P.span_vec && pos < nsamp;
+                f512_load4<DTYPE>(wave, valid ? s0 + pos : 0, xs[r]);
+                prevs[r] = dsp_load_sample<DTYPE>(wave, (valid && pos > 0) ? s0 + pos - 1 : 0);
             }
-            *reinterpret_cast<float4*>(wbuf + 4 * v) = y;
+#pragma unroll
+            for (int r = 0; r < NSTAGE; ++r) {
+                const int v = lane + 64 * r;
+                const int64_t pos = base + 4 * v;
+                const bool valid = v < P.span_vec && pos < nsamp;
+                const float prev = pos > 0 ? prevs[r] : 0.f;
+                float4 y;
+                y.x = valid ? fmaf(-P.preemph, prev, xs[r][0]) : 0.f;
+                y.y = valid ? fmaf(-P.preemph, xs[r][0], xs[r][1]) : 0.f;
+                y.z = valid ? fmaf(-P.preemph, xs[r][1], xs[r][2]) : 0.f;
+                y.w = valid ? fmaf(-P.preemph, xs[r][2], xs[r][3]) : 0.f;
+                if (v < P.span_vec) *reinterpret_cast<float4*>(wbuf + 4 * v) = y;
+            }
         }
         F512_FENCE();
 
@@ -246,20 +258,32 @@ __global__ __launch_bounds__(64 * WAVES) void mfcc512_kernel(F512Params P, Batch
         }
         F512_FENCE();
 
-        // ---- sparse mel triangles (table driven), log ----
+        // ---- sparse mel triangles, log.  Lane c owns filters c + 8 i; its weights sit in one LDS
+        //      row, the spectrum bins of a filter are contiguous from a 16-byte aligned start, so both
+        //      are read as b128.  Blocks of 8 taps: all reads are issued before the first FMA. ----
         float lm[NI];
         {
-            const float2* pg = s_prog + c;
-            const char* psb = reinterpret_cast<const char*>(ps);
+            const float4* wrow = reinterpret_cast<const float4*>(s_melw + c * P.melw_row);
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                float acc = 0.f;
-                const int n = P.len[i];
-                for (int s = 0; s < n; ++s) {
-                    const float2 e = *pg;
-                    pg += 8;
-                    acc = fmaf(e.x, *reinterpret_cast<const float*>(psb + __float_as_int(e.y)), acc);
+                const float4* pb = reinterpret_cast<const float4*>(ps + mel_start[i]);
+                float acc0 = 0.f, acc1 = 0.f;
+                const int nb = P.len[i] >> 3;
+                for (int b = 0; b < nb; ++b) {
+                    const float4 w0 = wrow[2 * b], w1 = wrow[2 * b + 1];
+                    const float4 q0 = pb[2 * b], q1 = pb[2 * b + 1];
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc0 = fmaf(w0.x, q0.x, acc0);
+                    acc1 = fmaf(w0.y, q0.y, acc1);
+                    acc0 = fmaf(w0.z, q0.z, acc0);
+                    acc1 = fmaf(w0.w, q0.w, acc1);
+                    acc0 = fmaf(w1.x, q1.x, acc0);
+                    acc1 = fmaf(w1.y, q1.y, acc1);
+                    acc0 = fmaf(w1.z, q1.z, acc0);
+                    acc1 = fmaf(w1.w, q1.w, acc1);
                 }
+                wrow += 2 * nb;
+                float acc = acc0 + acc1;
                 if (acc == 0.f) acc = DSP_EPS_F32;
                 lm[i] = __logf(acc);
             }
@@ -318,8 +342,9 @@ static inline int fast512_plan_init(dsp_plan* p, const dsp_plan_desc* d, const i
     const int M = d->nfilt, C = d->numcep, L = d->frame_len;
     const int ni_real = (M + 7) / 8, nrows = (L + 15) / 16;
     int variant, NI;  // template instantiation: <NROWS, NI, NC>
-    if (nrows <= 25 && ni_real <= 4 && C <= 13) { variant = 0; NI = 4; }
-    else if (nrows <= 25 && ni_real <= 5 && C <= 13) { variant = 1; NI = 5; }
+    const int nstage = ((7 * d->frame_step + L + 3) / 4 + 63) / 64;
+    if (nrows <= 25 && ni_real <= 4 && C <= 13 && nstage <= 6) { variant = 0; NI = 4; }
+    else if (nrows <= 25 && ni_real <= 5 && C <= 13 && nstage <= 6) { variant = 1; NI = 5; }
     else { variant = 2; NI = F512_MAX_NI; }
     std::vector<float> win(512, 0.f);
     for (int n = 0; n < L; ++n) win[n] = d->h_window[n];
@@ -340,39 +365,55 @@ static inline int fast512_plan_init(dsp_plan* p, const dsp_plan_desc* d, const i
         }
     Fast512Plan* fp = new Fast512Plan();
     memset(fp, 0, sizeof(*fp));
-    std::vector<float> prog;
-    int n_steps = 0;
+    // mel: per lane one row of weights (groups back to back); every filter starts on a bin that is
+    // a multiple of 4 (leading zero weights absorb the misalignment) and every group is padded to a
+    // multiple of 8 taps.  Padding weights are 0; padded reads stay inside the 264-float frame row.
+    int row_floats = 0;
     for (int i = 0; i < NI; ++i) {
         int len = 0;
         for (int c = 0; c < 8; ++c) {
             const int j = c + 8 * i;
-            if (j < M && d->h_mel_count[j] > len) len = d->h_mel_count[j];
+            if (j >= M) continue;
+            const int need = (d->h_mel_start[j] & 3) + d->h_mel_count[j];
+            if (need > len) len = need;
         }
+        len = (len + 7) / 8 * 8;
         fp->P.len[i] = len;
-        for (int s = 0; s < len; ++s)
-            for (int c = 0; c < 8; ++c) {
-                const int j = c + 8 * i;
-                float w = 0.f;
-                int32_t off = 0;
-                if (j < M && s < d->h_mel_count[j]) {
-                    w = d->h_mel_weights[mel_off[j] + s];
-                    off = 4 * (d->h_mel_start[j] + s);
+        row_floats += len;
+    }
+    int melw_row = row_floats > 0 ? row_floats : 8;
+    if (((melw_row / 4) & 1) == 0) melw_row += 4;  // odd number of 16-byte slots per row
+    std::vector<float> melw((size_t)8 * melw_row, 0.f), mels((size_t)NI * 8, 0.f);
+    for (int c = 0; c < 8; ++c) {
+        int pos = 0;
+        for (int i = 0; i < NI; ++i) {
+            const int j = c + 8 * i, len = fp->P.len[i];
+            int32_t start = 0;
+            if (j < M) {
+                start = d->h_mel_start[j] & ~3;
+                int lead = d->h_mel_start[j] - start;
+                if (start + len > F512_PS_STRIDE) {  // keep the padded read inside the row
+                    const int shift = (start + len - F512_PS_STRIDE + 3) / 4 * 4;
+                    start -= shift;
+                    lead += shift;
                 }
-                float offf;
-                memcpy(&offf, &off, 4);
-                prog.push_back(w);
-                prog.push_back(offf);
+                for (int s2 = 0; s2 < d->h_mel_count[j]; ++s2)
+                    melw[(size_t)c * melw_row + pos + lead + s2] = d->h_mel_weights[mel_off[j] + s2];
             }
-        n_steps += len;
+            memcpy(&mels[(size_t)i * 8 + c], &start, 4);
+            pos += len;
+        }
     }
     auto pad64 = [](size_t n) { return (n + 63) / 64 * 64; };
-    const size_t o_tw1 = 512, o_dct = o_tw1 + tw1.size(), o_prog = pad64(o_dct + dct.size());
-    const size_t total = pad64(o_prog + prog.size());
+    const size_t o_tw1 = 512, o_dct = o_tw1 + tw1.size(), o_melw = pad64(o_dct + dct.size());
+    const size_t o_mels = o_melw + melw.size();
+    const size_t total = pad64(o_mels + mels.size());
     std::vector<float> blob(total, 0.f);
     memcpy(blob.data(), win.data(), 512 * 4);
     memcpy(blob.data() + o_tw1, tw1.data(), tw1.size() * 4);
     memcpy(blob.data() + o_dct, dct.data(), dct.size() * 4);
-    if (!prog.empty()) memcpy(blob.data() + o_prog, prog.data(), prog.size() * 4);
+    memcpy(blob.data() + o_melw, melw.data(), melw.size() * 4);
+    memcpy(blob.data() + o_mels, mels.data(), mels.size() * 4);
     if (hipMalloc(reinterpret_cast<void**>(&fp->d_tables), total * 4) != hipSuccess ||
         hipMemcpy(fp->d_tables, blob.data(), total * 4, hipMemcpyHostToDevice) != hipSuccess) {
         delete fp;
@@ -380,7 +421,8 @@ static inline int fast512_plan_init(dsp_plan* p, const dsp_plan_desc* d, const i
     }
     fp->P.tables = fp->d_tables;
     fp->P.tab_floats = (int32_t)total;
-    fp->P.off_tw1 = (int32_t)o_tw1; fp->P.off_dct = (int32_t)o_dct; fp->P.off_prog = (int32_t)o_prog;
+    fp->P.off_tw1 = (int32_t)o_tw1; fp->P.off_dct = (int32_t)o_dct;
+    fp->P.off_melw = (int32_t)o_melw; fp->P.off_mels = (int32_t)o_mels; fp->P.melw_row = melw_row;
     fp->P.L = L; fp->P.S = d->frame_step; fp->P.M = M; fp->P.C = C;
     fp->P.append_energy = d->append_energy ? 1 : 0;
     fp->P.preemph = d->preemph;
@@ -406,17 +448,17 @@ static inline bool fast512_applicable(const dsp_plan* p, const BatchGeom& bg, co
     return (a % (dtype == DSP_WAVE_I16 ? 8 : 16)) == 0;
 }
 
-#define F512_WAVES 8
 
-template <int NROWS, int NI, int NC>
+template <int NROWS, int NI, int NC, int NSTAGE>
 static int fast512_launch_t(const Fast512Plan* fp, const F512Params& P, const void* d_wave, int dtype,
                             const BatchGeom& bg, float* d_out, int64_t ld_out, hipStream_t st) {
     const size_t lds = ((size_t)P.tab_floats + (size_t)F512_WAVES * F512_WAVE_FLOATS) * sizeof(float);
     int64_t blocks = (P.total_groups + F512_WAVES - 1) / F512_WAVES;
-    if (blocks > 512) blocks = 512;  // 256 CUs x 2 resident workgroups; waves grid-stride beyond
+    const int64_t cap = 256 * (16 / F512_WAVES);  // 256 CUs x resident workgroups (<= 16 waves per CU)
+    if (blocks > cap) blocks = cap;
     hipError_t e;
     if (dtype == DSP_WAVE_I16) {
-        auto k = mfcc512_kernel<NROWS, NI, NC, DSP_WAVE_I16, F512_WAVES>;
+        auto k = mfcc512_kernel<NROWS, NI, NC, NSTAGE, DSP_WAVE_I16, F512_WAVES>;
         static size_t lds_set = 0;  // raise the dynamic-LDS limit once per instantiation (and on growth)
         if (lds > lds_set) {
             e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -425,7 +467,7 @@ static int fast512_launch_t(const Fast512Plan* fp, const F512Params& P, const vo
         }
         k<<<(int)blocks, 64 * F512_WAVES, lds, st>>>(P, bg, d_wave, d_out, ld_out);
     } else {
-        auto k = mfcc512_kernel<NROWS, NI, NC, DSP_WAVE_F32, F512_WAVES>;
+        auto k = mfcc512_kernel<NROWS, NI, NC, NSTAGE, DSP_WAVE_F32, F512_WAVES>;
         static size_t lds_set = 0;
         if (lds > lds_set) {
             e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -444,7 +486,7 @@ static inline int fast512_launch(const dsp_plan* p, const void* d_wave, int dtyp
     P.groups_per_utt = (bg.uniform_frames + 7) / 8;
     P.total_groups = P.groups_per_utt * bg.n_utt;
     // exact instantiations for the common shapes, a padded catch-all otherwise (chosen at plan init)
-    if (fp->variant == 0) return fast512_launch_t<25, 4, 13>(fp, P, d_wave, dtype, bg, d_out, ld_out, st);
-    if (fp->variant == 1) return fast512_launch_t<25, 5, 13>(fp, P, d_wave, dtype, bg, d_out, ld_out, st);
-    return fast512_launch_t<32, 8, 16>(fp, P, d_wave, dtype, bg, d_out, ld_out, st);
+    if (fp->variant == 0) return fast512_launch_t<25, 4, 13, 6>(fp, P, d_wave, dtype, bg, d_out, ld_out, st);
+    if (fp->variant == 1) return fast512_launch_t<25, 5, 13, 6>(fp, P, d_wave, dtype, bg, d_out, ld_out, st);
+    return fast512_launch_t<32, 8, 16, 9>(fp, P, d_wave, dtype, bg, d_out, ld_out, st);
 }

@@ -227,6 +227,66 @@ __global__ __launch_bounds__(256) void delta_kernel(const float* __restrict__ in
     }
 }
 
+// Tiled delta + delta-delta: one workgroup owns DT_TILE consecutive frames of one utterance.
+// The tile's rows (plus a halo of 2N, edge-replicated at the utterance ends exactly like
+// numpy.pad(mode='edge') in base.py:75) go to LDS once; delta is formed in LDS for tile + halo N,
+// delta-delta from that, so every input value is read from HBM/L2 once instead of (2N+1)^2 times.
+#define DT_TILE 128
+__global__ __launch_bounds__(256) void delta_tiled_kernel(const float* __restrict__ in, int64_t ld_in, BatchGeom bg,
+                                                          int32_t D, int32_t N, float inv_den,
+                                                          float* __restrict__ out, int64_t ld_out,
+                                                          float* __restrict__ out_dd, int64_t ld_dd,
+                                                          int32_t tiles_per_utt_uniform,
+                                                          const int64_t* __restrict__ tile_off) {
+    extern __shared__ __attribute__((aligned(16))) float smem_d[];
+    // locate (utterance, tile)
+    int64_t base, T;
+    int32_t tile;
+    if (bg.uniform_frames > 0) {
+        const int64_t u = blockIdx.x / tiles_per_utt_uniform;
+        tile = (int32_t)(blockIdx.x - u * tiles_per_utt_uniform);
+        base = u * bg.uniform_frames;
+        T = bg.uniform_frames;
+    } else {
+        const int32_t u = dsp_find_utt(tile_off, bg.n_utt, (int64_t)blockIdx.x);
+        tile = (int32_t)(blockIdx.x - tile_off[u]);
+        base = bg.frame_off[u];
+        T = bg.frame_off[u + 1] - base;
+    }
+    const int t0 = tile * DT_TILE;
+    const int nt = (int)((T - t0) < DT_TILE ? (T - t0) : DT_TILE);  // frames of this tile
+    const int rows_x = nt + 4 * N, rows_d = nt + 2 * N;
+    float* sx = smem_d;                       // [rows_x][D]  x[clamp(t0 - 2N + r)]
+    float* sd = smem_d + (DT_TILE + 4 * N) * D;  // [rows_d][D]  delta[clamp(t0 - N + r)]
+    for (int i = threadIdx.x; i < rows_x * D; i += blockDim.x) {
+        const int r = i / D, d = i - r * D;
+        int64_t tt = (int64_t)t0 - 2 * N + r;
+        tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
+        sx[i] = in[(base + tt) * ld_in + d];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows_d * D; i += blockDim.x) {
+        const int r = i / D, d = i - r * D;
+        int64_t tt = (int64_t)t0 - N + r;           // requested frame; delta is evaluated at clamp(tt)
+        tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
+        const int rc = (int)(tt - t0) + 2 * N;     // row of x[tt] in sx
+        float acc = 0.f;
+        for (int n = 1; n <= N; ++n) acc = fmaf((float)n, sx[(rc + n) * D + d] - sx[(rc - n) * D + d], acc);
+        sd[i] = acc * inv_den;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nt * D; i += blockDim.x) {
+        const int r = i / D, d = i - r * D;
+        const int64_t g = base + t0 + r;
+        out[g * ld_out + d] = sd[(r + N) * D + d];
+        if (out_dd != nullptr) {
+            float acc = 0.f;
+            for (int n = 1; n <= N; ++n) acc = fmaf((float)n, sd[(r + N + n) * D + d] - sd[(r + N - n) * D + d], acc);
+            out_dd[g * ld_dd + d] = acc * inv_den;
+        }
+    }
+}
+
 template <int DTYPE>
 __global__ __launch_bounds__(256) void preemphasis_kernel(const void* __restrict__ wave, const int64_t* __restrict__ off,
                                                           int32_t n_utt, int64_t total, float coeff,

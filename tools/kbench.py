@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Kernel-level A/B harness: times the fused MFCC kernel (and the whole MFCC+delta step) for one or
+more builds of libdsp_frontend.so in ONE process per library (DSP_FRONTEND_LIB selects the build).
+
+    python tools/kbench.py [--reps 200] [--rounds 5]
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'dsp-speech-recognition_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--reps', type=int, default=200)
+    ap.add_argument('--rounds', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=1024)
+    ap.add_argument('--nfilt', type=int, default=40)
+    ap.add_argument('--streams', type=int, default=1)
+    args = ap.parse_args()
+    from features import _native as nat
+    from features.batch import FeaturePlan
+    dev = torch.device('cuda', 0)
+    B, N, T = args.batch, 16000, 99
+    plan = FeaturePlan(samplerate=16000, winlen=0.025, winstep=0.01, numcep=13, nfilt=args.nfilt, nfft=512,
+                       preemph=0.97, ceplifter=22, appendEnergy=True, winfunc=np.hamming)
+    layout = plan.layout(np.empty((B, N), dtype=np.float32))
+    g = torch.Generator(device=dev).manual_seed(1)
+    waves = [0.25 * torch.randn((B, N), device=dev, generator=g) for _ in range(8)]
+    out = torch.empty((B * T, 39), device=dev)
+    lib = nat.load()
+    st = torch.cuda.current_stream(dev)
+    streams = [torch.cuda.Stream(dev) for _ in range(args.streams)] if args.streams > 1 else [st]
+    outs = [torch.empty((B * T, 39), device=dev) for _ in streams]
+
+    def mfcc_only(i):
+        k = i % len(streams)
+        nat.check(lib.dsp_features_batch(plan.plan.handle, waves[i % 8].data_ptr(), nat.WAVE_F32, None, None, B,
+                                         B * T, N, nat.OUT_MFCC, outs[k].data_ptr(), 39, None,
+                                         streams[k].cuda_stream))
+
+    def full(i):
+        k = i % len(streams)
+        plan.run_raw(waves[i % 8].data_ptr(), nat.WAVE_F32, layout, outs[k].data_ptr(), 2, streams[k].cuda_stream)
+
+    res = {}
+    for name, fn in (('mfcc', mfcc_only), ('mfcc+delta', full)):
+        for i in range(10):
+            fn(i)
+        times = []
+        for _ in range(args.rounds):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record(st)
+            for s_ in streams:
+                s_.wait_event(e0)
+            for i in range(args.reps):
+                fn(i)
+            for s_ in streams:
+                ev = torch.cuda.Event()
+                ev.record(s_)
+                st.wait_event(ev)
+            e1.record(st)
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1) / args.reps)
+        res[name] = (float(np.median(times)), float(np.min(times)))
+    fr = B * T
+    print(f"{os.path.basename(nat.LIB_PATH):34s} mfcc {res['mfcc'][0]*1e3:7.1f} us (min {res['mfcc'][1]*1e3:6.1f}) "
+          f"= {fr/res['mfcc'][0]/1e6:6.2f} Gframes/s | +delta {res['mfcc+delta'][0]*1e3:7.1f} us "
+          f"= {fr/res['mfcc+delta'][0]/1e6:6.2f} Gframes/s | streams={len(streams)}")
+
+
+if __name__ == '__main__':
+    main()
