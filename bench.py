@@ -46,16 +46,23 @@ def synth_batch(seed):
 
 
 def _oracle_worker(args):
+    """Run the oracle on `count` synthetic utterances (generated in chunks, generation not timed)."""
     seed, count = args
     from oracle import dsp_oracle
-    x = synth_batch(seed)[:count].astype(np.float64)
-    t0 = time.perf_counter()
-    for b in range(count):
-        dsp_oracle.mfcc_delta(x[b], delta_n=DELTA_N, winfunc=np.hamming, **CFG)
-    return time.perf_counter() - t0, count * T
+    busy, done = 0.0, 0
+    while done < count:
+        n = min(B, count - done)
+        x = synth_batch(seed)[:n].astype(np.float64)
+        seed += 7919
+        t0 = time.perf_counter()
+        for b in range(n):
+            dsp_oracle.mfcc_delta(x[b], delta_n=DELTA_N, winfunc=np.hamming, **CFG)
+        busy += time.perf_counter() - t0
+        done += n
+    return busy, count * T
 
 
-def cpu_baseline(budget_s=12.0):
+def cpu_baseline(budget_s=8.0):
     """The NumPy oracle (parity-pinned port of the reference's path) timed on this box's host cores
     on a bounded sample of the same workload: all cores via multiprocessing, plus 1 core."""
     import multiprocessing as mp
@@ -65,19 +72,18 @@ def cpu_baseline(budget_s=12.0):
     per_utt = dt / 64
     single = frames / dt
     cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 64))
-    per_worker = int(max(16, min(B, budget_s / per_utt)))
+    cores = max(1, min(cores, 16))   # the GPU box's CPU share for one GPU
+    per_worker = int(max(16, min(32 * B, budget_s / per_utt)))
     ctx = mp.get_context('spawn')
     with ctx.Pool(cores) as pool:
         pool.map(_oracle_worker, [(i, 2) for i in range(cores)])   # warm the workers (imports)
-        t0 = time.perf_counter()
         res = pool.map(_oracle_worker, [(100 + i, per_worker) for i in range(cores)])
-        wall = time.perf_counter() - t0
     total_frames = sum(r[1] for r in res)
+    busy = max(r[0] for r in res)   # workers run concurrently; the slowest one bounds the rate
     return {
-        'value': total_frames / wall, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
-        'sample': f'{cores} workers x {per_worker} utterances (1 s, 16 kHz) of the same synthetic '
-                  f'workload, NumPy oracle mfcc+delta+delta2, wall {wall:.1f} s',
+        'value': total_frames / busy, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+        'sample': f'{cores} processes x {per_worker} utterances (1 s, 16 kHz) of the same synthetic '
+                  f'workload, NumPy oracle mfcc+delta+delta2, {busy:.1f} s of CPU work per process',
         'single_core_value': single,
     }
 
@@ -88,6 +94,7 @@ def main():
     ap.add_argument('--steps', type=int, default=400)
     ap.add_argument('--warmup', type=int, default=40)
     ap.add_argument('--buffers', type=int, default=8, help='distinct input batches rotated over (x65.5 MB)')
+    ap.add_argument('--streams', type=int, default=2, help='HIP streams the independent steps alternate over')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gather', action='store_true')
     args = ap.parse_args()
@@ -119,13 +126,17 @@ def main():
     waves = [torch.from_numpy(host0).to(dev)]
     for i in range(1, args.buffers):
         waves.append(torch.from_numpy(synth_batch(rank * 1000 + i)).to(dev))
-    outs = [torch.empty((B * T, D), dtype=torch.float32, device=dev) for _ in range(min(args.buffers, 4))]
     stream = torch.cuda.current_stream(dev)
     sp = stream.cuda_stream
+    # Steps are independent (own input batch, own output buffer), so consecutive steps alternate over
+    # `--streams` HIP streams: the tail of one launch overlaps the head of the next.
+    streams = [torch.cuda.Stream(dev) for _ in range(args.streams)] if args.streams > 1 else [stream]
+    outs = [torch.empty((B * T, D), dtype=torch.float32, device=dev) for _ in range(max(4, len(streams)))]
 
     def step(i):
+        k = i % len(streams)
         plan.run_raw(waves[i % len(waves)].data_ptr(), nat.WAVE_F32, layout, outs[i % len(outs)].data_ptr(),
-                     DELTA_N, sp)
+                     DELTA_N, streams[k].cuda_stream)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -205,6 +216,7 @@ def main():
         'config': {'workload': 'configs[1]: batch of 1024 synthetic 1 s 16 kHz utterances -> MFCC+delta+delta2 '
                                '[1024*99, 39] per step per GPU', 'utterances_per_step_per_gpu': B,
                    'frames_per_utterance': T, 'delta_n': DELTA_N, 'input_buffers_rotated': len(waves),
+                   'hip_streams': len(streams),
                    'sharding': f'{world} ranks x independent batches, no data-path collective'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,

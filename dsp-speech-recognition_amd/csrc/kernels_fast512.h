@@ -30,6 +30,9 @@
 #ifndef F512_WAVES
 #define F512_WAVES 8
 #endif
+#ifndef F512_PREFETCH
+#define F512_PREFETCH 1
+#endif
 #ifndef F512_MIN_WAVES_PER_SIMD
 #define F512_MIN_WAVES_PER_SIMD 2
 #endif
@@ -66,15 +69,80 @@ __device__ __forceinline__ float frame_allreduce(float v) {
 
 #define F512_FENCE() asm volatile("" ::: "memory")
 
-template <int DTYPE>
-__device__ __forceinline__ void f512_load4(const void* __restrict__ wave, int64_t idx, float (&x)[4]) {
-    if constexpr (DTYPE == DSP_WAVE_I16) {
-        const short4 v = *reinterpret_cast<const short4*>(reinterpret_cast<const int16_t*>(wave) + idx);
-        x[0] = (float)v.x; x[1] = (float)v.y; x[2] = (float)v.z; x[3] = (float)v.w;
-    } else {
-        const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(wave) + idx);
-        x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+typedef float f512_v2 __attribute__((ext_vector_type(2)));
+// Plain ds_read_b64 (2 LDS cycles per wave, 64-bank addressing).  hipcc would pair neighbouring
+// b64 reads into ds_read2_b64, which costs 8 cycles and uses 32-bank addressing -- with frames
+// 160 floats apart that is a 2-way conflict on top.  The caller waits with F512_LDS_WAIT().
+template <int OFF_BYTES>
+__device__ __forceinline__ f512_v2 f512_lds_read_b64(uint32_t addr) {
+    f512_v2 v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF_BYTES));
+    return v;
+}
+// hipcc may hoist register-only arithmetic above an asm wait ("memory" does not order it):
+// the sched_barrier pins everything that follows behind the wait.
+#define F512_LDS_WAIT()                                   \
+    do {                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_sched_barrier(0);                \
+    } while (0)
+__device__ __forceinline__ uint32_t f512_lds_addr(const void* p) {
+    return static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p));
+}
+
+template <int N, int R, int ROW0>
+__device__ __forceinline__ void f512_load_rows(uint32_t fr, uint32_t wn, f512_v2 (&xv)[N], f512_v2 (&wv)[N]) {
+    if constexpr (R < N) {  // rows ROW0 .. ROW0 + N - 1, 64 bytes apart
+        xv[R] = f512_lds_read_b64<64 * (ROW0 + R)>(fr);
+        wv[R] = f512_lds_read_b64<64 * (ROW0 + R)>(wn);
+        f512_load_rows<N, R + 1, ROW0>(fr, wn, xv, wv);
     }
+}
+
+// One staged vector = 4 consecutive samples as they sit in HBM (16 B of fp32 or 8 B of int16).
+template <int DTYPE> struct F512Raw { float4 v; };
+template <> struct F512Raw<DSP_WAVE_I16> { short4 v; };
+
+template <int DTYPE>
+__device__ __forceinline__ F512Raw<DTYPE> f512_load_raw(const void* __restrict__ wave_utt, uint32_t off) {
+    // wave_utt: first sample of the utterance (wave-uniform), off: sample offset inside it
+    F512Raw<DTYPE> r;
+    if constexpr (DTYPE == DSP_WAVE_I16) r.v = *reinterpret_cast<const short4*>(reinterpret_cast<const int16_t*>(wave_utt) + off);
+    else r.v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(wave_utt) + off);
+    return r;
+}
+template <int DTYPE>
+__device__ __forceinline__ void f512_unpack(const F512Raw<DTYPE>& r, float (&x)[4]) {
+    x[0] = (float)r.v.x; x[1] = (float)r.v.y; x[2] = (float)r.v.z; x[3] = (float)r.v.w;
+}
+template <int DTYPE>
+__device__ __forceinline__ const void* f512_utt_ptr(const void* __restrict__ wave, int64_t s0) {
+    if constexpr (DTYPE == DSP_WAVE_I16) return reinterpret_cast<const int16_t*>(wave) + s0;
+    else return reinterpret_cast<const float*>(wave) + s0;
+}
+// lane l receives lane l-1's value; lane 0 receives `left`.  DPP wave_shr:1 -- one VALU op, no LDS
+// (verified on gfx950 hardware with tools/probes/dpp_probe.hip).
+__device__ __forceinline__ float f512_shift_in(float v, float left) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(left), __float_as_int(v), 0x138, 0xF, 0xF, false));
+}
+
+// Issue the NSTAGE staging loads of group G (no waits): samples base .. base + 4*span_vec of its utterance.
+template <int NSTAGE, int DTYPE>
+__device__ __forceinline__ void f512_issue_loads(const void* __restrict__ wave, int64_t nsamp, int groups_per_utt,
+                                                 int S, int span_vec, int G, int lane,
+                                                 F512Raw<DTYPE> (&raw)[NSTAGE], float& prev_in) {
+    const int utt = G / groups_per_utt;
+    const int base = (G - utt * groups_per_utt) * 8 * S;
+    const void* up = f512_utt_ptr<DTYPE>(wave, (int64_t)utt * nsamp);
+    const int ns = (int)nsamp;
+#pragma unroll
+    for (int r = 0; r < NSTAGE; ++r) {
+        const int v = lane + 64 * r;
+        const int pos = base + 4 * v;
+        const bool valid = v < span_vec && pos < ns;
+        raw[r] = f512_load_raw<DTYPE>(up, valid ? (uint32_t)pos : 0u);
+    }
+    prev_in = base > 0 ? dsp_load_sample<DTYPE>(up, base - 1) : 0.f;
 }
 
 template <int NROWS, int NI, int NC, int NSTAGE, int DTYPE, int WAVES>
@@ -92,7 +160,7 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
     const float* s_dct = smem + P.off_dct;
     const float* s_melw = smem + P.off_melw;
 
-    const int wid = tid >> 6, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int f = lane >> 3, c = lane & 7;
     float* wbuf = smem + P.tab_floats + wid * F512_WAVE_FLOATS;
     const int sigma_hi = ((f >> 1) & 1) << 2;  // exchange swizzle: slot ^= (u >> 1) ^ sigma_hi
@@ -102,56 +170,75 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
 #pragma unroll
     for (int i = 0; i < NI; ++i) mel_start[i] = __float_as_int(smem[P.off_mels + i * 8 + (tid & 7)]);
 
-    for (int64_t G = (int64_t)blockIdx.x * WAVES + wid; G < P.total_groups; G += (int64_t)gridDim.x * WAVES) {
-        const int64_t utt = G / P.groups_per_utt;
-        const int t0 = (int)(G - utt * P.groups_per_utt) * 8;
-        const int64_t s0 = utt * nsamp;
-        const int64_t base = (int64_t)t0 * P.S;
+    const int gpu = (int)P.groups_per_utt, total_groups = (int)P.total_groups;
+    const int gstride = (int)gridDim.x * WAVES;
+    int G = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WAVES + wid);
+    F512Raw<DTYPE> raw[NSTAGE];
+    float prev_in = 0.f;
+#if F512_PREFETCH
+    if (G < total_groups) f512_issue_loads<NSTAGE, DTYPE>(wave, nsamp, gpu, P.S, P.span_vec, G, lane, raw, prev_in);
+#endif
 
-        // ---- stage 7 S + L samples: coalesced 16 B loads (all issued before the first use),
-        //      pre-emphasis, zero fill past the end.  pos and nsamp are multiples of 4, so a 16-byte
-        //      vector is either entirely inside the utterance or entirely padding. ----
+    for (; G < total_groups; G += gstride) {
+        const int utt = G / gpu;
+        const int t0 = (G - utt * gpu) * 8;
+        const int base = t0 * P.S;
+
+        // ---- stage 7 S + L samples (loaded from HBM one iteration ahead, 16 B per lane, coalesced):
+        //      pre-emphasis, zero fill past the end.  base and nsamp are multiples of 4, so a vector is
+        //      either entirely inside the utterance or entirely padding. ----
         {
-            float xs[NSTAGE][4], prevs[NSTAGE];
+#if !F512_PREFETCH
+            f512_issue_loads<NSTAGE, DTYPE>(wave, nsamp, gpu, P.S, P.span_vec, G, lane, raw, prev_in);
+#endif
+            float left = prev_in;
 #pragma unroll
             for (int r = 0; r < NSTAGE; ++r) {
                 const int v = lane + 64 * r;
-                const int64_t pos = base + 4 * v;
-                const bool valid = v < P.span_vec && pos < nsamp;
-                f512_load4<DTYPE>(wave, valid ? s0 + pos : 0, xs[r]);
-                prevs[r] = dsp_load_sample<DTYPE>(wave, (valid && pos > 0) ? s0 + pos - 1 : 0);
-            }
-#pragma unroll
-            for (int r = 0; r < NSTAGE; ++r) {
-                const int v = lane + 64 * r;
-                const int64_t pos = base + 4 * v;
-                const bool valid = v < P.span_vec && pos < nsamp;
-                const float prev = pos > 0 ? prevs[r] : 0.f;
+                const int pos = base + 4 * v;
+                const bool valid = v < P.span_vec && pos < (int)nsamp;
+                float x[4];
+                f512_unpack<DTYPE>(raw[r], x);
+                const float prev = f512_shift_in(x[3], left);   // sample pos - 1 (0 before the utterance)
+                left = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[3]), 63));
                 float4 y;
-                y.x = valid ? fmaf(-P.preemph, prev, xs[r][0]) : 0.f;
-                y.y = valid ? fmaf(-P.preemph, xs[r][0], xs[r][1]) : 0.f;
-                y.z = valid ? fmaf(-P.preemph, xs[r][1], xs[r][2]) : 0.f;
-                y.w = valid ? fmaf(-P.preemph, xs[r][2], xs[r][3]) : 0.f;
+                y.x = valid ? fmaf(-P.preemph, prev, x[0]) : 0.f;
+                y.y = valid ? fmaf(-P.preemph, x[0], x[1]) : 0.f;
+                y.z = valid ? fmaf(-P.preemph, x[1], x[2]) : 0.f;
+                y.w = valid ? fmaf(-P.preemph, x[2], x[3]) : 0.f;
                 if (v < P.span_vec) *reinterpret_cast<float4*>(wbuf + 4 * v) = y;
             }
         }
+#if F512_PREFETCH
+        // prefetch the next group's samples; they land while this group is being transformed
+        if (G + gstride < total_groups)
+            f512_issue_loads<NSTAGE, DTYPE>(wave, nsamp, gpu, P.S, P.span_vec, G + gstride, lane, raw, prev_in);
+#endif
         F512_FENCE();
 
         // ---- pass 1: window, complex FFT32 over n1 of (column 2c) + i (column 2c+1) ----
         cpx z[32];
         {
-            const float* fr = wbuf + f * P.S + 2 * c;
-            const float* wn = s_win + 2 * c;
+            const uint32_t fr = f512_lds_addr(wbuf + f * P.S + 2 * c);
+            const uint32_t wn = f512_lds_addr(s_win + 2 * c);
+            // two batches of rows: all reads of a batch are in flight before its first multiply
+            constexpr int H = (NROWS + 1) / 2;
+            {
+                f512_v2 xv[H], wv[H];
+                f512_load_rows<H, 0, 0>(fr, wn, xv, wv);
+                F512_LDS_WAIT();
 #pragma unroll
-            for (int n1 = 0; n1 < 32; ++n1) {
-                if (n1 < NROWS) {
-                    const float2 xv = *reinterpret_cast<const float2*>(fr + 16 * n1);
-                    const float2 wv = *reinterpret_cast<const float2*>(wn + 16 * n1);
-                    z[n1] = {xv.x * wv.x, xv.y * wv.y};
-                } else {
-                    z[n1] = {0.f, 0.f};
-                }
+                for (int n1 = 0; n1 < H; ++n1) z[n1] = {xv[n1].x * wv[n1].x, xv[n1].y * wv[n1].y};
             }
+            {
+                f512_v2 xv[NROWS - H], wv[NROWS - H];
+                f512_load_rows<NROWS - H, 0, H>(fr, wn, xv, wv);
+                F512_LDS_WAIT();
+#pragma unroll
+                for (int n1 = H; n1 < NROWS; ++n1) z[n1] = {xv[n1 - H].x * wv[n1 - H].x, xv[n1 - H].y * wv[n1 - H].y};
+            }
+#pragma unroll
+            for (int n1 = NROWS; n1 < 32; ++n1) z[n1] = {0.f, 0.f};
         }
         FFTReg<32>::template run<NROWS>(z);
         F512_FENCE();
@@ -296,7 +383,7 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         for (int k = 0; k < NC; ++k) cep[k] = 0.f;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const float4* dr = reinterpret_cast<const float4*>(s_dct + (i * 8 + c) * 16);
+            const float4* dr = reinterpret_cast<const float4*>(s_dct + (i * 8 + c) * 20);
 #pragma unroll
             for (int q = 0; q < (NC + 3) / 4; ++q) {
                 const float4 d = dr[q];
@@ -319,7 +406,7 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         }
         const int t = t0 + f;
         if (t < T) {
-            float* o = out + (utt * T + t) * ld_out;
+            float* o = out + ((int64_t)utt * T + t) * ld_out;
             if (c < P.C) o[c] = v0;
             if (c + 8 < P.C) o[c + 8] = v1;
         }
@@ -356,12 +443,12 @@ static inline int fast512_plan_init(dsp_plan* p, const dsp_plan_desc* d, const i
                 tw1[((k1 - 1) * 8 + c) * 4 + 2 * h] = (float)cos(a);
                 tw1[((k1 - 1) * 8 + c) * 4 + 2 * h + 1] = (float)sin(a);
             }
-    std::vector<float> dct((size_t)NI * 8 * 16, 0.f);
+    std::vector<float> dct((size_t)NI * 8 * 20, 0.f);  // 20-float rows: 5 x 16 B, conflict-free b128
     for (int i = 0; i < NI; ++i)
         for (int c = 0; c < 8; ++c) {
             const int j = c + 8 * i;
             if (j >= M) continue;
-            for (int k = 0; k < C; ++k) dct[((size_t)i * 8 + c) * 16 + k] = d->h_dct[(size_t)k * M + j];
+            for (int k = 0; k < C; ++k) dct[((size_t)i * 8 + c) * 20 + k] = d->h_dct[(size_t)k * M + j];
         }
     Fast512Plan* fp = new Fast512Plan();
     memset(fp, 0, sizeof(*fp));
@@ -444,6 +531,7 @@ static inline void fast512_plan_free(dsp_plan* p) {
 static inline bool fast512_applicable(const dsp_plan* p, const BatchGeom& bg, const void* d_wave, int dtype) {
     if (!p->d_fast) return false;
     if (bg.uniform_samples <= 0 || (bg.uniform_samples % 4) != 0) return false;
+    if (bg.uniform_samples > 0x3fffffff || ((bg.uniform_frames + 7) / 8) * bg.n_utt > 0x3fffffff) return false;  // 32-bit indexing
     const uintptr_t a = reinterpret_cast<uintptr_t>(d_wave);
     return (a % (dtype == DSP_WAVE_I16 ? 8 : 16)) == 0;
 }

@@ -1,0 +1,131 @@
+"""GPU parity, part 2: batched entry points at BASELINE.json's sizes and the properties that do not
+need the oracle at full size.  Everything goes through the C ABI (features.batch -> ctypes)."""
+import numpy as np
+import pytest
+
+from conftest import normwise
+from oracle import dsp_oracle
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(samplerate=16000, winlen=0.025, winstep=0.01, numcep=13, nfilt=40, nfft=512, lowfreq=0,
+           highfreq=None, preemph=0.97, ceplifter=22, appendEnergy=True)
+FB_CFG = {k: v for k, v in CFG.items() if k not in ('numcep', 'ceplifter', 'appendEnergy')}
+TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def plan():
+    from features.batch import FeaturePlan
+    return FeaturePlan(winfunc=np.hamming, **CFG)
+
+
+def _batch(seed, B, N=16000, dtype=np.float32):
+    rng = np.random.default_rng(seed)
+    if dtype == np.int16:
+        return np.clip(np.round(3000 * rng.standard_normal((B, N))), -32768, 32767).astype(np.int16)
+    return (0.25 * rng.standard_normal((B, N))).astype(np.float32)
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.int16])
+def test_config2_batch_1024_vs_oracle(plan, dtype):
+    """configs[1]: 1024 x 1 s -> [1024*99, 39]; every wave iterates over several frame groups."""
+    B = 1024
+    waves = _batch(11, B, dtype=dtype)
+    out, fo = plan.mfcc_batch(waves, delta_n=2)
+    assert out.shape == (B * 99, 39) and fo[-1] == B * 99
+    assert np.isfinite(out).all()
+    worst = 0.0
+    for b in list(range(0, B, 37)) + [B - 1]:
+        ref = dsp_oracle.mfcc_delta(waves[b].astype(np.float64), delta_n=2, winfunc=np.hamming, **CFG)
+        worst = max(worst, normwise(out[fo[b]:fo[b + 1]], ref))
+    assert worst <= TOL, worst
+
+
+def test_batch_equals_single_calls(plan):
+    """Sharding invariance: an utterance's features do not depend on its batch neighbours."""
+    import features
+    B = 300
+    waves = _batch(12, B)
+    out, fo = plan.mfcc_batch(waves, delta_n=0)
+    for b in (0, 1, 149, 299):
+        single = features.mfcc(waves[b], winfunc=np.hamming, **CFG)
+        assert np.array_equal(out[fo[b]:fo[b + 1]], single.astype(np.float32)), b
+
+
+def test_generic_and_fast_kernels_agree(plan):
+    """The specialised NFFT=512 kernel and the table-driven generic kernel are independent
+    implementations; a ragged batch (generic path) must match the uniform batch (fast path)."""
+    B, N = 64, 16000
+    waves = _batch(13, B, N)
+    out_fast, _ = plan.mfcc_batch(waves, delta_n=2)
+    tail = _batch(14, 1, 4000)[0]   # one short utterance makes the layout ragged
+    flat = np.concatenate([waves.reshape(-1), tail])
+    so = np.concatenate([np.arange(B + 1) * N, [B * N + 4000]]).astype(np.int64)
+    out_gen, fo = plan.mfcc_batch(flat, sample_offsets=so, delta_n=2)
+    assert fo[B] == B * 99
+    assert normwise(out_gen[:B * 99], out_fast) <= 5e-5  # two fp32 pipelines, each ~1e-5 from fp64
+
+
+def test_ragged_batch_vs_oracle(plan):
+    rng = np.random.default_rng(15)
+    lens = [16000, 300, 400, 401, 12345, 8000, 559, 16001, 32000, 1]
+    so = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    flat = (0.25 * rng.standard_normal(so[-1])).astype(np.float32)
+    out, fo = plan.mfcc_batch(flat, sample_offsets=so, delta_n=2)
+    for b, n in enumerate(lens):
+        ref = dsp_oracle.mfcc_delta(flat[so[b]:so[b + 1]].astype(np.float64), delta_n=2, winfunc=np.hamming, **CFG)
+        assert out[fo[b]:fo[b + 1]].shape == ref.shape
+        assert normwise(out[fo[b]:fo[b + 1]], ref) <= TOL, (b, n)
+
+
+def test_parseval_full_size():
+    """Oracle-free property: sum_n frame[n]^2 == pspec[0] + 2 sum_{0<k<256} pspec[k] + pspec[256]
+     on an 8 s signal through the framesig / powspec kernels."""
+    import features
+    x = _batch(16, 1, 16000 * 8)[0].astype(np.float64)
+    frames = features.framesig(x, 400, 160, np.hamming)
+    ps = features.powspec(frames, 512)
+    lhs = np.sum(frames ** 2, axis=1)
+    rhs = ps[:, 0] + 2 * ps[:, 1:256].sum(axis=1) + ps[:, 256]
+    assert np.max(np.abs(lhs - rhs) / np.max(lhs)) <= 2e-6
+
+
+def test_quadratic_scaling_of_fbank():
+    """fbank energies are quadratic: scaling the waveform by a scales feat and energy by a^2."""
+    import features
+    x = _batch(17, 1)[0].astype(np.float64)
+    f1, e1 = features.fbank(x, winfunc=np.hamming, **FB_CFG)
+    f2, e2 = features.fbank(4.0 * x, winfunc=np.hamming, **FB_CFG)
+    assert normwise(f2, 16.0 * f1) <= 1e-5 and normwise(e2, 16.0 * e1) <= 1e-5
+
+
+def test_known_answers():
+    """DC -> only bin 0; alternating +-1 -> ZCR = L - 1; framesig row t == sig[t*S : t*S+L];
+    delta of a ramp == slope in the interior; delta(N < 1) raises like the reference."""
+    import features
+    ps = features.powspec(np.ones((3, 512)), 512)
+    assert np.allclose(ps[:, 0], 512.0, rtol=1e-6) and np.max(np.abs(ps[:, 1:])) < 1e-6
+    alt = np.tile(np.array([1, -1], dtype=np.int16), 240)[None, :]
+    assert features.get_zcr(alt) == [479]
+    x = np.arange(4000, dtype=np.float64)
+    fr = features.framesig(x, 400, 160)
+    assert np.array_equal(fr[3], x[480:880]) and fr.shape == (24, 400)
+    ramp = np.outer(np.arange(50, dtype=np.float64), np.ones(4)) * 0.5
+    d = features.delta(ramp, 2)
+    assert np.allclose(d[2:-2], 0.5, atol=1e-6)
+    with pytest.raises(ValueError):
+        features.delta(ramp, 0)
+
+
+def test_endpoint_batch_matches_single():
+    from features.batch import EndpointPlan
+    from golden_cases import make_signal
+    import features
+    clips = [make_signal(('vad', 50 + i, 16000 + 800 * i)) for i in range(12)]
+    so = np.concatenate([[0], np.cumsum([len(c) for c in clips])]).astype(np.int64)
+    ep = EndpointPlan(16000, 0.03, 0.01)
+    got = ep.detect_batch(np.concatenate(clips), sample_offsets=so)
+    for b, c in enumerate(clips):
+        assert tuple(got[b]) == features.basic_endpoint_detection(c, 16000)
+        assert tuple(got[b]) == dsp_oracle.basic_endpoint_detection(c, 16000)
