@@ -192,7 +192,7 @@ def main():
     # --- configs[2]: RCCL all-gather of one step's features, timed on its own ---
     gather = None
     if world > 1 and not args.no_gather:
-        gbuf = torch.empty((world, B * T, D), dtype=torch.float32, device=dev)
+        gbuf = torch.empty((world * B * T, D), dtype=torch.float32, device=dev)
         for _ in range(2):
             dist.all_gather_into_tensor(gbuf, outs[0])
         sync_all()
@@ -204,6 +204,16 @@ def main():
         gms = (time.perf_counter() - g0) / reps * 1e3
         gather = {'collective': 'rccl all_gather_into_tensor', 'bytes_per_rank': B * T * D * 4, 'ms': gms,
                   'algbw_GBps': world * B * T * D * 4 / gms / 1e6}
+
+    # HBM traffic per launch measured with rocprofv3 PMC passes (cannot be collected inside this process)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r1_traffic.json')) as fh:
+            tj = json.load(fh)
+        if tj.get('frames_per_launch') == B * T:
+            traffic = tj['traffic_bytes_per_launch']
+    except (OSError, ValueError, KeyError):
+        traffic = None
 
     frames_total = float(world) * B * T * args.steps
     value = frames_total / dt
@@ -219,7 +229,8 @@ def main():
                    'hip_streams': len(streams),
                    'sharding': f'{world} ranks x independent batches, no data-path collective'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+                     'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
+                     'algorithmic_bytes_per_launch': BYTES_PER_FRAME_MFCC * B * T,
                      'kernel': 'fused MFCC kernel (dsp_features_batch, DSP_OUT_MFCC)',
                      'kernel_ms': kernel_ms, 'bytes_per_frame': BYTES_PER_FRAME_MFCC,
                      'frames_per_launch': B * T,
