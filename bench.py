@@ -94,7 +94,7 @@ def main():
     ap.add_argument('--steps', type=int, default=400)
     ap.add_argument('--warmup', type=int, default=40)
     ap.add_argument('--buffers', type=int, default=8, help='distinct input batches rotated over (x65.5 MB)')
-    ap.add_argument('--streams', type=int, default=2, help='HIP streams the independent steps alternate over')
+    ap.add_argument('--streams', type=int, default=3, help='HIP streams the independent steps alternate over')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gather', action='store_true')
     args = ap.parse_args()

@@ -336,8 +336,13 @@ int dsp_delta_batch(const float* d_in, int64_t ld_in, const int64_t* d_frame_off
         const int64_t tiles = (uniform_frames + DT_TILE - 1) / DT_TILE;
         const int64_t blocks = tiles * n_utt;
         if (blocks > 0x7fffffff) return fail(DSP_EINVAL, "too many delta tiles");
-        delta_tiled_kernel<<<(int)blocks, 256, lds, (hipStream_t)stream>>>(
-            d_in, ld_in, bg, D, N, inv_den, d_out, ld_out, d_out_dd, ld_out_dd, (int32_t)tiles, nullptr);
+        if (ld_in > 0x7fffff || ld_out > 0x7fffff || ld_out_dd > 0x7fffff) return fail(DSP_EINVAL, "row stride too large");
+        if (D == 13)
+            delta_tiled_kernel<13><<<(int)blocks, 256, lds, (hipStream_t)stream>>>(
+                d_in, ld_in, bg, D, N, inv_den, d_out, ld_out, d_out_dd, ld_out_dd, (int32_t)tiles, nullptr);
+        else
+            delta_tiled_kernel<0><<<(int)blocks, 256, lds, (hipStream_t)stream>>>(
+                d_in, ld_in, bg, D, N, inv_den, d_out, ld_out, d_out_dd, ld_out_dd, (int32_t)tiles, nullptr);
     } else {
         delta_kernel<<<grid_for(n_frames_total * D, 256), 256, 0, (hipStream_t)stream>>>(
             d_in, ld_in, bg, D, N, inv_den, d_out, ld_out, d_out_dd, ld_out_dd);

@@ -118,6 +118,9 @@ struct Stage1 {  // 4-point DFTs over a (n = (N/4) a + b), for b = B .. N/4-1
         cpx t0 = x[B], t1 = x[NB + B], t2 = x[2 * NB + B], t3 = x[3 * NB + B];
         dft4<nz_of<NZ, NB, B>()>(t0, t1, t2, t3);
         y[B][0] = t0; y[B][1] = t1; y[B][2] = t2; y[B][3] = t3;
+#if defined(__HIP_DEVICE_COMPILE__) && defined(FFT_SEQ_BARRIERS)
+        if constexpr ((B & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // bound live ranges: 2 butterflies in flight
+#endif
         if constexpr (B + 1 < NB) Stage1<N, NZ, B + 1>::run(x, y);
     }
 };
@@ -141,6 +144,9 @@ struct FFTReg {
             FFTReg<NB>::run(u);
 #pragma unroll
             for (int e = 0; e < NB; ++e) x[d + 4 * e] = u[e];
+#if defined(__HIP_DEVICE_COMPILE__) && defined(FFT_SEQ_BARRIERS)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
     }
 };

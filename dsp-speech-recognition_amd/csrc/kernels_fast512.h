@@ -31,10 +31,10 @@
 #define F512_WAVES 8
 #endif
 #ifndef F512_PREFETCH
-#define F512_PREFETCH 1
+#define F512_PREFETCH 0
 #endif
 #ifndef F512_MIN_WAVES_PER_SIMD
-#define F512_MIN_WAVES_PER_SIMD 2
+#define F512_MIN_WAVES_PER_SIMD 4
 #endif
 
 struct F512Params {
@@ -160,15 +160,10 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
     const float* s_dct = smem + P.off_dct;
     const float* s_melw = smem + P.off_melw;
 
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int f = lane >> 3, c = lane & 7;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* wbuf = smem + P.tab_floats + wid * F512_WAVE_FLOATS;
-    const int sigma_hi = ((f >> 1) & 1) << 2;  // exchange swizzle: slot ^= (u >> 1) ^ sigma_hi
     const int T = (int)bg.uniform_frames;
     const int64_t nsamp = bg.uniform_samples;
-    int mel_start[NI];  // first FFT bin of this lane's filter in group i (kept in registers)
-#pragma unroll
-    for (int i = 0; i < NI; ++i) mel_start[i] = __float_as_int(smem[P.off_mels + i * 8 + (tid & 7)]);
 
     const int gpu = (int)P.groups_per_utt, total_groups = (int)P.total_groups;
     const int gstride = (int)gridDim.x * WAVES;
@@ -176,10 +171,16 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
     F512Raw<DTYPE> raw[NSTAGE];
     float prev_in = 0.f;
 #if F512_PREFETCH
-    if (G < total_groups) f512_issue_loads<NSTAGE, DTYPE>(wave, nsamp, gpu, P.S, P.span_vec, G, lane, raw, prev_in);
+    if (G < total_groups) f512_issue_loads<NSTAGE, DTYPE>(wave, nsamp, gpu, P.S, P.span_vec, G, tid & 63, raw, prev_in);
 #endif
 
     for (; G < total_groups; G += gstride) {
+        // Lane-derived addresses are recomputed every iteration on purpose: hoisted out of the loop
+        // they would pin ~30 VGPRs for the whole kernel (the opaque asm stops the hoisting).
+        int lane = tid & 63;
+        asm volatile("" : "+v"(lane));
+        const int f = lane >> 3, c = lane & 7;
+        const int sigma_hi = ((f >> 1) & 1) << 2;  // exchange swizzle: slot ^= (u >> 1) ^ sigma_hi
         const int utt = G / gpu;
         const int t0 = (G - utt * gpu) * 8;
         const int base = t0 * P.S;
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
             const float4* wrow = reinterpret_cast<const float4*>(s_melw + c * P.melw_row);
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                const float4* pb = reinterpret_cast<const float4*>(ps + mel_start[i]);
+                const float4* pb = reinterpret_cast<const float4*>(ps + __float_as_int(smem[P.off_mels + i * 8 + c]));
                 float acc0 = 0.f, acc1 = 0.f;
                 const int nb = P.len[i] >> 3;
                 for (int b = 0; b < nb; ++b) {

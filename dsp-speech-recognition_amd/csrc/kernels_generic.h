@@ -232,57 +232,62 @@ __global__ __launch_bounds__(256) void delta_kernel(const float* __restrict__ in
 // numpy.pad(mode='edge') in base.py:75) go to LDS once; delta is formed in LDS for tile + halo N,
 // delta-delta from that, so every input value is read from HBM/L2 once instead of (2N+1)^2 times.
 #define DT_TILE 128
+template <int DC>  // DC > 0: feature width known at compile time (division by a constant); 0: runtime D
 __global__ __launch_bounds__(256) void delta_tiled_kernel(const float* __restrict__ in, int64_t ld_in, BatchGeom bg,
-                                                          int32_t D, int32_t N, float inv_den,
+                                                          int32_t D_rt, int32_t N, float inv_den,
                                                           float* __restrict__ out, int64_t ld_out,
                                                           float* __restrict__ out_dd, int64_t ld_dd,
                                                           int32_t tiles_per_utt_uniform,
                                                           const int64_t* __restrict__ tile_off) {
     extern __shared__ __attribute__((aligned(16))) float smem_d[];
-    // locate (utterance, tile)
-    int64_t base, T;
-    int32_t tile;
+    const int D = DC > 0 ? DC : D_rt;
+    // locate (utterance, tile): wave-uniform scalars
+    int64_t base;
+    int T, tile;
     if (bg.uniform_frames > 0) {
-        const int64_t u = blockIdx.x / tiles_per_utt_uniform;
-        tile = (int32_t)(blockIdx.x - u * tiles_per_utt_uniform);
-        base = u * bg.uniform_frames;
-        T = bg.uniform_frames;
+        const int u = (int)blockIdx.x / tiles_per_utt_uniform;
+        tile = (int)blockIdx.x - u * tiles_per_utt_uniform;
+        base = (int64_t)u * bg.uniform_frames;
+        T = (int)bg.uniform_frames;
     } else {
         const int32_t u = dsp_find_utt(tile_off, bg.n_utt, (int64_t)blockIdx.x);
         tile = (int32_t)(blockIdx.x - tile_off[u]);
         base = bg.frame_off[u];
-        T = bg.frame_off[u + 1] - base;
+        T = (int)(bg.frame_off[u + 1] - base);
     }
     const int t0 = tile * DT_TILE;
-    const int nt = (int)((T - t0) < DT_TILE ? (T - t0) : DT_TILE);  // frames of this tile
+    const int nt = (T - t0) < DT_TILE ? (T - t0) : DT_TILE;  // frames of this tile
     const int rows_x = nt + 4 * N, rows_d = nt + 2 * N;
-    float* sx = smem_d;                       // [rows_x][D]  x[clamp(t0 - 2N + r)]
-    float* sd = smem_d + (DT_TILE + 4 * N) * D;  // [rows_d][D]  delta[clamp(t0 - N + r)]
-    for (int i = threadIdx.x; i < rows_x * D; i += blockDim.x) {
+    const int ldi = (int)ld_in, ldo = (int)ld_out, ldd = (int)ld_dd;
+    const float* in_u = in + base * ld_in;        // utterance-relative 32-bit offsets from here on
+    float* out_u = out + (base + t0) * ld_out;
+    float* dd_u = out_dd ? out_dd + (base + t0) * ld_dd : nullptr;
+    float* sx = smem_d;                           // [rows_x][D]  x[clamp(t0 - 2N + r)]
+    float* sd = smem_d + (DT_TILE + 4 * N) * D;   // [rows_d][D]  delta[clamp(t0 - N + r)]
+    for (int i = threadIdx.x; i < rows_x * D; i += 256) {
         const int r = i / D, d = i - r * D;
-        int64_t tt = (int64_t)t0 - 2 * N + r;
+        int tt = t0 - 2 * N + r;
         tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
-        sx[i] = in[(base + tt) * ld_in + d];
+        sx[i] = in_u[tt * ldi + d];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < rows_d * D; i += blockDim.x) {
+    for (int i = threadIdx.x; i < rows_d * D; i += 256) {
         const int r = i / D, d = i - r * D;
-        int64_t tt = (int64_t)t0 - N + r;           // requested frame; delta is evaluated at clamp(tt)
+        int tt = t0 - N + r;                       // requested frame; delta is evaluated at clamp(tt)
         tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
-        const int rc = (int)(tt - t0) + 2 * N;     // row of x[tt] in sx
+        const int rc = tt - t0 + 2 * N;            // row of x[tt] in sx
         float acc = 0.f;
         for (int n = 1; n <= N; ++n) acc = fmaf((float)n, sx[(rc + n) * D + d] - sx[(rc - n) * D + d], acc);
         sd[i] = acc * inv_den;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nt * D; i += blockDim.x) {
+    for (int i = threadIdx.x; i < nt * D; i += 256) {
         const int r = i / D, d = i - r * D;
-        const int64_t g = base + t0 + r;
-        out[g * ld_out + d] = sd[(r + N) * D + d];
-        if (out_dd != nullptr) {
+        out_u[r * ldo + d] = sd[(r + N) * D + d];
+        if (dd_u != nullptr) {
             float acc = 0.f;
             for (int n = 1; n <= N; ++n) acc = fmaf((float)n, sd[(r + N + n) * D + d] - sd[(r + N - n) * D + d], acc);
-            out_dd[g * ld_dd + d] = acc * inv_den;
+            dd_u[r * ldd + d] = acc * inv_den;
         }
     }
 }
