@@ -202,12 +202,14 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
                 f512_unpack<DTYPE>(raw[r], x);
                 const float prev = f512_shift_in(x[3], left);   // sample pos - 1 (0 before the utterance)
                 left = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[3]), 63));
+                const uint32_t m = valid ? 0xffffffffu : 0u;   // zero fill: one select + 4 full-rate ANDs
                 float4 y;
-                y.x = valid ? fmaf(-P.preemph, prev, x[0]) : 0.f;
-                y.y = valid ? fmaf(-P.preemph, x[0], x[1]) : 0.f;
-                y.z = valid ? fmaf(-P.preemph, x[1], x[2]) : 0.f;
-                y.w = valid ? fmaf(-P.preemph, x[2], x[3]) : 0.f;
-                if (v < P.span_vec) *reinterpret_cast<float4*>(wbuf + 4 * v) = y;
+                y.x = __uint_as_float(__float_as_uint(fmaf(-P.preemph, prev, x[0])) & m);
+                y.y = __uint_as_float(__float_as_uint(fmaf(-P.preemph, x[0], x[1])) & m);
+                y.z = __uint_as_float(__float_as_uint(fmaf(-P.preemph, x[1], x[2])) & m);
+                y.w = __uint_as_float(__float_as_uint(fmaf(-P.preemph, x[2], x[3])) & m);
+                // rounds past the span write zeros inside this wave's own buffer when it is large enough
+                if (NSTAGE * 256 <= F512_WAVE_FLOATS || v < P.span_vec) *reinterpret_cast<float4*>(wbuf + 4 * v) = y;
             }
         }
 #if F512_PREFETCH
@@ -300,20 +302,28 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         FFTReg<16>::run(u1);
 
         // power spectrum |X|^2 / 512 (rows carry a factor 2 -> 1/2048)
-        float p0[16], p1[16], p256 = 0.f;
+        float p0[16], p1[16];
         constexpr float S1 = 1.0f / 2048.0f, S2 = 1.0f / 32768.0f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             p0[k] = S1 * fmaf(u0[k].x, u0[k].x, u0[k].y * u0[k].y);
             p1[k] = S1 * fmaf(u1[k].x, u1[k].x, u1[k].y * u1[k].y);
         }
+        // Slot layout of p0 (unit 0): p0[k] -> bin c + 32 k (k < 8), bin 512 - 32 k - c (k >= 8).
+        // Lane 0 (c = 0) owns bins 16 j instead: the even ones (32 k) fit the same slots, bin 256 is
+        // slot 8, slots 9..15 repeat bins 224..32, and the 8 odd ones (16, 48, .., 240) go to podd[].
+        float podd[8];
+        float esum0 = 0.f;  // lane 0: sum over its 17 distinct bins
+#pragma unroll
+        for (int m = 0; m < 8; ++m) podd[m] = 0.f;
         if (c == 0) {
-            // lane 0, slot 0: u0 = FFT16 of r[2m] + i r[2m+1]; finish the 32-point real FFT:
-            // bins 16 j, j = 0..16 (factor 8 carried -> 1/32768)
+            // u0 = FFT16 of r[2m] + i r[2m+1]; finish the 32-point real FFT R[j] = X[16 j], j = 0..16
+            // (factor 8 carried -> 1/32768)
+            float R[17];
             const float e0 = u0[0].x + u0[0].y, e16 = u0[0].x - u0[0].y;
-            p0[0] = S2 * 4.f * e0 * e0;
-            p256 = S2 * 4.f * e16 * e16;
-            p0[8] = S2 * 4.f * fmaf(u0[8].x, u0[8].x, u0[8].y * u0[8].y);
+            R[0] = S2 * 4.f * e0 * e0;
+            R[16] = S2 * 4.f * e16 * e16;
+            R[8] = S2 * 4.f * fmaf(u0[8].x, u0[8].x, u0[8].y * u0[8].y);
 #pragma unroll
             for (int j = 1; j < 8; ++j) {
                 const cpx zj = u0[j], zq = u0[16 - j];
@@ -323,26 +333,45 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
                 const cpx tw = cmulc(o, DSP_COS32[j], -DSP_SIN32[j]);  // W32^j * o
                 const cpx rp = {e.x + tw.x, e.y + tw.y};
                 const cpx rm = {e.x - tw.x, e.y - tw.y};
-                p0[j] = S2 * fmaf(rp.x, rp.x, rp.y * rp.y);
-                p0[16 - j] = S2 * fmaf(rm.x, rm.x, rm.y * rm.y);
+                R[j] = S2 * fmaf(rp.x, rp.x, rp.y * rp.y);
+                R[16 - j] = S2 * fmaf(rm.x, rm.x, rm.y * rm.y);
+            }
+#pragma unroll
+            for (int j = 0; j < 17; ++j) esum0 += R[j];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                p0[k] = R[2 * k];
+                p0[8 + k] = R[16 - 2 * k];
+                podd[k] = R[2 * k + 1];
             }
         }
-        float energy = p256;
+        float energy = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) energy += p0[k] + p1[k];
+        if (c == 0) {
+            energy = esum0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) energy += p1[k];
+        }
         energy = frame_allreduce(energy);
         if (energy == 0.f) energy = DSP_EPS_F32;
 
-        // ---- power spectrum -> LDS row of this frame ----
+        // ---- power spectrum -> LDS row of this frame: two base registers, immediate offsets ----
         float* ps = wbuf + f * F512_PS_STRIDE;
         {
-            const int lo0 = c, st0 = c ? 32 : 16, hi0 = c ? 512 - c : 0, sh0 = c ? -32 : 16;
+            float* lo = ps + c;           // bins c + 32 k           (+8 for unit 1)
+            float* hi = ps + 32 - c;      // bins 512 - 32 k - c = (32 - c) + 32 (15 - k)   (-8 for unit 1)
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                ps[k < 8 ? lo0 + st0 * k : hi0 + sh0 * k] = p0[k];
-                ps[k < 8 ? (c + 8) + 32 * k : 512 - 32 * k - (c + 8)] = p1[k];
+            for (int k = 0; k < 8; ++k) {
+                lo[32 * k] = p0[k];
+                hi[32 * (7 - k)] = p0[8 + k];
+                lo[32 * k + 8] = p1[k];
+                hi[32 * (7 - k) - 8] = p1[8 + k];
             }
-            if (c == 0) ps[256] = p256;
+            if (c == 0) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) ps[32 * m + 16] = podd[m];
+            }
         }
         F512_FENCE();
 
@@ -542,9 +571,13 @@ template <int NROWS, int NI, int NC, int NSTAGE>
 static int fast512_launch_t(const Fast512Plan* fp, const F512Params& P, const void* d_wave, int dtype,
                             const BatchGeom& bg, float* d_out, int64_t ld_out, hipStream_t st) {
     const size_t lds = ((size_t)P.tab_floats + (size_t)F512_WAVES * F512_WAVE_FLOATS) * sizeof(float);
-    int64_t blocks = (P.total_groups + F512_WAVES - 1) / F512_WAVES;
+    // balanced persistent grid: every wave runs the same number of groups (no ragged last round)
     const int64_t cap = 256 * (16 / F512_WAVES);  // 256 CUs x resident workgroups (<= 16 waves per CU)
-    if (blocks > cap) blocks = cap;
+    int64_t blocks = (P.total_groups + F512_WAVES - 1) / F512_WAVES;
+    if (blocks > cap) {
+        const int64_t rounds = (blocks + cap - 1) / cap;
+        blocks = (blocks + rounds - 1) / rounds;
+    }
     hipError_t e;
     if (dtype == DSP_WAVE_I16) {
         auto k = mfcc512_kernel<NROWS, NI, NC, NSTAGE, DSP_WAVE_I16, F512_WAVES>;
