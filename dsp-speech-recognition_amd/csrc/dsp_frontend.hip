@@ -1,6 +1,7 @@
 // C ABI of libdsp_frontend.so (see include/dsp_frontend.h).  gfx950 / ROCm only.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -15,6 +16,7 @@
 namespace {
 
 thread_local std::string g_err;
+std::atomic<int> g_force_generic{0};
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -105,6 +107,13 @@ GenericParams generic_params(const dsp_plan* p) {
 extern "C" {
 
 int dsp_abi_version(void) { return DSP_ABI_VERSION; }
+
+int dsp_debug_force_generic(int on) {
+    g_force_generic.store(on ? 1 : 0);
+    return DSP_OK;
+}
+
+int dsp_plan_has_fast_path(const dsp_plan* plan) { return plan && plan->d_fast ? 1 : 0; }
 
 const char* dsp_last_error(void) { return g_err.c_str(); }
 
@@ -306,7 +315,7 @@ int dsp_features_batch(const dsp_plan* plan, const void* d_wave, int wave_dtype,
     if (uniform_samples > 0 && bg.uniform_frames * n_utt != n_frames_total)
         return fail(DSP_EINVAL, "n_frames_total %lld != n_utt*T (%d*%lld)", (long long)n_frames_total, n_utt, (long long)bg.uniform_frames);
     hipStream_t st = (hipStream_t)stream;
-    if (out_kind == DSP_OUT_MFCC && fast512_applicable(plan, bg, d_wave, wave_dtype))
+    if (out_kind == DSP_OUT_MFCC && !g_force_generic.load() && fast512_applicable(plan, bg, d_wave, wave_dtype))
         return fast512_launch(plan, d_wave, wave_dtype, bg, d_out, ld_out, st);
     return launch_generic(plan, d_wave, wave_dtype, bg, out_kind, d_out, ld_out, d_out2, st);
 }
@@ -343,6 +352,22 @@ int dsp_delta_batch(const float* d_in, int64_t ld_in, const int64_t* d_frame_off
         else
             delta_tiled_kernel<0><<<(int)blocks, 256, lds, (hipStream_t)stream>>>(
                 d_in, ld_in, bg, D, N, inv_den, d_out, ld_out, d_out_dd, ld_out_dd, (int32_t)tiles, nullptr);
+    } else if (uniform_frames <= 0 && lds <= 64 * 1024 && ld_in <= 0x7fffff && ld_out <= 0x7fffff && ld_out_dd <= 0x7fffff) {
+        // ragged: per-utterance tile prefix in a stream-ordered scratch buffer, grid sized by a bound
+        static_assert(DT_TILE == 128, "shift below assumes 128-frame tiles");
+        const int64_t bound = n_frames_total / DT_TILE + n_utt;
+        if (bound > 0x7fffffff) return fail(DSP_EINVAL, "too many delta tiles");
+        int64_t* tile_off = nullptr;
+        hipStream_t st = (hipStream_t)stream;
+        HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&tile_off), ((size_t)n_utt + 1) * sizeof(int64_t), st));
+        prefix_ceil_kernel<<<1, 1024, 0, st>>>(d_frame_offsets, n_utt, 7, tile_off);
+        if (D == 13)
+            delta_tiled_kernel<13><<<(int)bound, 256, lds, st>>>(d_in, ld_in, bg, D, N, inv_den, d_out, ld_out,
+                                                                 d_out_dd, ld_out_dd, 0, tile_off);
+        else
+            delta_tiled_kernel<0><<<(int)bound, 256, lds, st>>>(d_in, ld_in, bg, D, N, inv_den, d_out, ld_out,
+                                                                d_out_dd, ld_out_dd, 0, tile_off);
+        HIP_TRY(hipFreeAsync(tile_off, st));
     } else {
         delta_kernel<<<grid_for(n_frames_total * D, 256), 256, 0, (hipStream_t)stream>>>(
             d_in, ld_in, bg, D, N, inv_den, d_out, ld_out, d_out_dd, ld_out_dd);

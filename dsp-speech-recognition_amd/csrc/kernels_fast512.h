@@ -30,9 +30,6 @@
 #ifndef F512_WAVES
 #define F512_WAVES 8
 #endif
-#ifndef F512_PREFETCH
-#define F512_PREFETCH 0
-#endif
 #ifndef F512_MIN_WAVES_PER_SIMD
 #define F512_MIN_WAVES_PER_SIMD 4
 #endif
@@ -46,7 +43,9 @@ struct F512Params {
     float preemph;
     int32_t span_vec;      // ceil((7 S + L) / 4): 16-byte vectors staged per wave
     int32_t len[F512_MAX_NI];  // padded (multiple of 8) taps per filter group
-    int64_t groups_per_utt, total_groups;
+    int64_t groups_per_utt, total_groups;   // uniform batches
+    const int32_t* group_off;                // ragged: [B+1] prefix of ceil(T_b / 8)
+    const int32_t* group_utt;                // ragged: utterance of every frame group
 };
 
 struct Fast512Plan {
@@ -104,21 +103,16 @@ template <int DTYPE> struct F512Raw { float4 v; };
 template <> struct F512Raw<DSP_WAVE_I16> { short4 v; };
 
 template <int DTYPE>
-__device__ __forceinline__ F512Raw<DTYPE> f512_load_raw(const void* __restrict__ wave_utt, uint32_t off) {
-    // wave_utt: first sample of the utterance (wave-uniform), off: sample offset inside it
+__device__ __forceinline__ F512Raw<DTYPE> f512_load_raw(const void* __restrict__ wave, int64_t idx) {
+    // idx: element index (multiple of 4) in the concatenated waveform buffer
     F512Raw<DTYPE> r;
-    if constexpr (DTYPE == DSP_WAVE_I16) r.v = *reinterpret_cast<const short4*>(reinterpret_cast<const int16_t*>(wave_utt) + off);
-    else r.v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(wave_utt) + off);
+    if constexpr (DTYPE == DSP_WAVE_I16) r.v = *reinterpret_cast<const short4*>(reinterpret_cast<const int16_t*>(wave) + idx);
+    else r.v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(wave) + idx);
     return r;
 }
 template <int DTYPE>
 __device__ __forceinline__ void f512_unpack(const F512Raw<DTYPE>& r, float (&x)[4]) {
     x[0] = (float)r.v.x; x[1] = (float)r.v.y; x[2] = (float)r.v.z; x[3] = (float)r.v.w;
-}
-template <int DTYPE>
-__device__ __forceinline__ const void* f512_utt_ptr(const void* __restrict__ wave, int64_t s0) {
-    if constexpr (DTYPE == DSP_WAVE_I16) return reinterpret_cast<const int16_t*>(wave) + s0;
-    else return reinterpret_cast<const float*>(wave) + s0;
 }
 // lane l receives lane l-1's value; lane 0 receives `left`.  DPP wave_shr:1 -- one VALU op, no LDS
 // (verified on gfx950 hardware with tools/probes/dpp_probe.hip).
@@ -126,26 +120,38 @@ __device__ __forceinline__ float f512_shift_in(float v, float left) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(left), __float_as_int(v), 0x138, 0xF, 0xF, false));
 }
 
-// Issue the NSTAGE staging loads of group G (no waits): samples base .. base + 4*span_vec of its utterance.
-template <int NSTAGE, int DTYPE>
-__device__ __forceinline__ void f512_issue_loads(const void* __restrict__ wave, int64_t nsamp, int groups_per_utt,
-                                                 int S, int span_vec, int G, int lane,
-                                                 F512Raw<DTYPE> (&raw)[NSTAGE], float& prev_in) {
-    const int utt = G / groups_per_utt;
-    const int base = (G - utt * groups_per_utt) * 8 * S;
-    const void* up = f512_utt_ptr<DTYPE>(wave, (int64_t)utt * nsamp);
-    const int ns = (int)nsamp;
-#pragma unroll
-    for (int r = 0; r < NSTAGE; ++r) {
-        const int v = lane + 64 * r;
-        const int pos = base + 4 * v;
-        const bool valid = v < span_vec && pos < ns;
-        raw[r] = f512_load_raw<DTYPE>(up, valid ? (uint32_t)pos : 0u);
+// Where a frame group lives (all wave-uniform).
+struct F512Group {
+    int utt, t0, T, nsamp;
+    int64_t s0, row0;
+};
+
+template <bool RAGGED>
+__device__ __forceinline__ F512Group f512_locate(const F512Params& P, const BatchGeom& bg, int G) {
+    F512Group g;
+    if constexpr (RAGGED) {
+        g.utt = P.group_utt[G];
+        g.t0 = (G - P.group_off[g.utt]) * 8;
+        g.s0 = bg.sample_off[g.utt];
+        g.nsamp = (int)(bg.sample_off[g.utt + 1] - g.s0);
+        g.row0 = bg.frame_off[g.utt];
+        g.T = (int)(bg.frame_off[g.utt + 1] - g.row0);
+    } else {
+        const int gpu = (int)P.groups_per_utt;
+        g.utt = G / gpu;
+        g.t0 = (G - g.utt * gpu) * 8;
+        g.nsamp = (int)bg.uniform_samples;
+        g.T = (int)bg.uniform_frames;
+        g.s0 = (int64_t)g.utt * bg.uniform_samples;
+        g.row0 = (int64_t)g.utt * bg.uniform_frames;
     }
-    prev_in = base > 0 ? dsp_load_sample<DTYPE>(up, base - 1) : 0.f;
+    return g;
 }
 
-template <int NROWS, int NI, int NC, int NSTAGE, int DTYPE, int WAVES>
+// RAGGED = false: dense [B, N] batch, N % 4 == 0 (every 16-byte vector is all-valid or all-padding).
+// RAGGED = true : concatenated utterances of any length at any offset; loads stay 16-byte aligned
+//                 (the LDS image starts at the aligned sample below the group's first one).
+template <int NROWS, int NI, int NC, int NSTAGE, int DTYPE, int WAVES, bool RAGGED>
 __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_kernel(F512Params P, BatchGeom bg,
                                                              const void* __restrict__ wave,
                                                              float* __restrict__ out, int64_t ld_out) {
@@ -162,83 +168,106 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
 
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* wbuf = smem + P.tab_floats + wid * F512_WAVE_FLOATS;
-    const int T = (int)bg.uniform_frames;
-    const int64_t nsamp = bg.uniform_samples;
-
-    const int gpu = (int)P.groups_per_utt, total_groups = (int)P.total_groups;
+    const int total_groups = RAGGED ? P.group_off[bg.n_utt] : (int)P.total_groups;
     const int gstride = (int)gridDim.x * WAVES;
-    int G = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WAVES + wid);
-    F512Raw<DTYPE> raw[NSTAGE];
-    float prev_in = 0.f;
-#if F512_PREFETCH
-    if (G < total_groups) f512_issue_loads<NSTAGE, DTYPE>(wave, nsamp, gpu, P.S, P.span_vec, G, tid & 63, raw, prev_in);
-#endif
 
-    for (; G < total_groups; G += gstride) {
+    for (int G = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WAVES + wid); G < total_groups; G += gstride) {
         // Lane-derived addresses are recomputed every iteration on purpose: hoisted out of the loop
         // they would pin ~30 VGPRs for the whole kernel (the opaque asm stops the hoisting).
         int lane = tid & 63;
         asm volatile("" : "+v"(lane));
         const int f = lane >> 3, c = lane & 7;
         const int sigma_hi = ((f >> 1) & 1) << 2;  // exchange swizzle: slot ^= (u >> 1) ^ sigma_hi
-        const int utt = G / gpu;
-        const int t0 = (G - utt * gpu) * 8;
-        const int base = t0 * P.S;
+        const F512Group grp = f512_locate<RAGGED>(P, bg, G);
+        const int utt = grp.utt, t0 = grp.t0, T = grp.T, nsamp = grp.nsamp;
+        (void)utt;
+        const int base = t0 * P.S;                            // first sample of the group, utterance relative
+        const int64_t g0 = grp.s0 + base;                     // ... in the concatenated buffer
+        const int d = RAGGED ? (int)(g0 & 3) : 0;             // LDS image starts d samples earlier (aligned)
 
-        // ---- stage 7 S + L samples (loaded from HBM one iteration ahead, 16 B per lane, coalesced):
-        //      pre-emphasis, zero fill past the end.  base and nsamp are multiples of 4, so a vector is
-        //      either entirely inside the utterance or entirely padding. ----
+        // ---- stage 7 S + L (+ d) samples: coalesced aligned 16 B loads, all issued before first use;
+        //      pre-emphasis, zero fill outside the utterance. ----
         {
-#if !F512_PREFETCH
-            f512_issue_loads<NSTAGE, DTYPE>(wave, nsamp, gpu, P.S, P.span_vec, G, lane, raw, prev_in);
-#endif
-            float left = prev_in;
+            const int64_t a0 = g0 - d;                         // aligned element index of LDS slot 0
+            const int span_vec = RAGGED ? P.span_vec + 1 : P.span_vec;
+            F512Raw<DTYPE> raw[NSTAGE];
 #pragma unroll
             for (int r = 0; r < NSTAGE; ++r) {
                 const int v = lane + 64 * r;
-                const int pos = base + 4 * v;
-                const bool valid = v < P.span_vec && pos < (int)nsamp;
+                const int rel = base - d + 4 * v;             // utterance-relative position of element 0
+                const bool touch = v < span_vec && rel + 3 >= 0 && rel < nsamp;  // >= 1 valid element
+                // an aligned vector holding >= 1 valid sample never leaves a mapped page; idle lanes
+                // re-read the start of the buffer
+                raw[r] = f512_load_raw<DTYPE>(wave, touch ? a0 + 4 * v : 0);
+            }
+            float left = (base - d > 0) ? dsp_load_sample<DTYPE>(wave, a0 - 1) : 0.f;
+#pragma unroll
+            for (int r = 0; r < NSTAGE; ++r) {
+                const int v = lane + 64 * r;
+                const int rel = base - d + 4 * v;
                 float x[4];
                 f512_unpack<DTYPE>(raw[r], x);
-                const float prev = f512_shift_in(x[3], left);   // sample pos - 1 (0 before the utterance)
+                const float prev = f512_shift_in(x[3], left);   // sample rel - 1
                 left = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[3]), 63));
-                const uint32_t m = valid ? 0xffffffffu : 0u;   // zero fill: one select + 4 full-rate ANDs
                 float4 y;
-                y.x = __uint_as_float(__float_as_uint(fmaf(-P.preemph, prev, x[0])) & m);
-                y.y = __uint_as_float(__float_as_uint(fmaf(-P.preemph, x[0], x[1])) & m);
-                y.z = __uint_as_float(__float_as_uint(fmaf(-P.preemph, x[1], x[2])) & m);
-                y.w = __uint_as_float(__float_as_uint(fmaf(-P.preemph, x[2], x[3])) & m);
+                y.x = fmaf(-P.preemph, prev, x[0]);
+                y.y = fmaf(-P.preemph, x[0], x[1]);
+                y.z = fmaf(-P.preemph, x[1], x[2]);
+                y.w = fmaf(-P.preemph, x[2], x[3]);
+                if constexpr (RAGGED) {
+                    // the utterance may start / end inside this vector: first sample is not filtered,
+                    // everything outside [0, nsamp) is zero
+                    if (rel + 0 == 0) y.x = x[0];
+                    if (rel + 1 == 0) y.y = x[1];
+                    if (rel + 2 == 0) y.z = x[2];
+                    if (rel + 3 == 0) y.w = x[3];
+                    if (rel + 0 < 0 || rel + 0 >= nsamp) y.x = 0.f;
+                    if (rel + 1 < 0 || rel + 1 >= nsamp) y.y = 0.f;
+                    if (rel + 2 < 0 || rel + 2 >= nsamp) y.z = 0.f;
+                    if (rel + 3 < 0 || rel + 3 >= nsamp) y.w = 0.f;
+                } else {
+                    const uint32_t m = (v < span_vec && rel < nsamp) ? 0xffffffffu : 0u;  // one select + 4 ANDs
+                    y.x = __uint_as_float(__float_as_uint(y.x) & m);
+                    y.y = __uint_as_float(__float_as_uint(y.y) & m);
+                    y.z = __uint_as_float(__float_as_uint(y.z) & m);
+                    y.w = __uint_as_float(__float_as_uint(y.w) & m);
+                }
                 // rounds past the span write zeros inside this wave's own buffer when it is large enough
-                if (NSTAGE * 256 <= F512_WAVE_FLOATS || v < P.span_vec) *reinterpret_cast<float4*>(wbuf + 4 * v) = y;
+                if (NSTAGE * 256 <= F512_WAVE_FLOATS || v < span_vec) *reinterpret_cast<float4*>(wbuf + 4 * v) = y;
             }
         }
-#if F512_PREFETCH
-        // prefetch the next group's samples; they land while this group is being transformed
-        if (G + gstride < total_groups)
-            f512_issue_loads<NSTAGE, DTYPE>(wave, nsamp, gpu, P.S, P.span_vec, G + gstride, lane, raw, prev_in);
-#endif
         F512_FENCE();
 
         // ---- pass 1: window, complex FFT32 over n1 of (column 2c) + i (column 2c+1) ----
         cpx z[32];
         {
-            const uint32_t fr = f512_lds_addr(wbuf + f * P.S + 2 * c);
+            const float* frp = wbuf + d + f * P.S + 2 * c;
+            const uint32_t fr = f512_lds_addr(frp);
             const uint32_t wn = f512_lds_addr(s_win + 2 * c);
-            // two batches of rows: all reads of a batch are in flight before its first multiply
-            constexpr int H = (NROWS + 1) / 2;
-            {
-                f512_v2 xv[H], wv[H];
-                f512_load_rows<H, 0, 0>(fr, wn, xv, wv);
-                F512_LDS_WAIT();
+            if (RAGGED && (d & 1)) {
+                // odd offset inside the aligned LDS image: the column pair is not 8-byte aligned
 #pragma unroll
-                for (int n1 = 0; n1 < H; ++n1) z[n1] = {xv[n1].x * wv[n1].x, xv[n1].y * wv[n1].y};
-            }
-            {
-                f512_v2 xv[NROWS - H], wv[NROWS - H];
-                f512_load_rows<NROWS - H, 0, H>(fr, wn, xv, wv);
-                F512_LDS_WAIT();
+                for (int n1 = 0; n1 < NROWS; ++n1) {
+                    const float2 wv = *reinterpret_cast<const float2*>(s_win + 2 * c + 16 * n1);
+                    z[n1] = {frp[16 * n1] * wv.x, frp[16 * n1 + 1] * wv.y};
+                }
+            } else {
+                // two batches of rows: all reads of a batch are in flight before its first multiply
+                constexpr int H = (NROWS + 1) / 2;
+                {
+                    f512_v2 xv[H], wv[H];
+                    f512_load_rows<H, 0, 0>(fr, wn, xv, wv);
+                    F512_LDS_WAIT();
 #pragma unroll
-                for (int n1 = H; n1 < NROWS; ++n1) z[n1] = {xv[n1 - H].x * wv[n1 - H].x, xv[n1 - H].y * wv[n1 - H].y};
+                    for (int n1 = 0; n1 < H; ++n1) z[n1] = {xv[n1].x * wv[n1].x, xv[n1].y * wv[n1].y};
+                }
+                {
+                    f512_v2 xv[NROWS - H], wv[NROWS - H];
+                    f512_load_rows<NROWS - H, 0, H>(fr, wn, xv, wv);
+                    F512_LDS_WAIT();
+#pragma unroll
+                    for (int n1 = H; n1 < NROWS; ++n1) z[n1] = {xv[n1 - H].x * wv[n1 - H].x, xv[n1 - H].y * wv[n1 - H].y};
+                }
             }
 #pragma unroll
             for (int n1 = NROWS; n1 < 32; ++n1) z[n1] = {0.f, 0.f};
@@ -436,12 +465,44 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         }
         const int t = t0 + f;
         if (t < T) {
-            float* o = out + ((int64_t)utt * T + t) * ld_out;
+            float* o = out + (grp.row0 + t) * ld_out;
             if (c < P.C) o[c] = v0;
             if (c + 8 < P.C) o[c + 8] = v1;
         }
         F512_FENCE();
     }
+}
+
+// Ragged batches: group_off[b] = sum_{i<b} ceil(T_i / 8) (exclusive prefix, single block), then the
+// utterance of every group.  Both are tiny next to the main kernel and run on the same stream.
+__global__ __launch_bounds__(1024) void f512_group_prefix_kernel(const int64_t* __restrict__ frame_off, int32_t n_utt,
+                                                                 int32_t* __restrict__ group_off) {
+    __shared__ int32_t part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n_utt + 1023) / 1024;
+    const int lo = tid * per, hi = min(lo + per, n_utt);
+    int32_t sum = 0;
+    for (int b = lo; b < hi; ++b) sum += (int32_t)((frame_off[b + 1] - frame_off[b] + 7) >> 3);
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan of the per-thread sums
+        const int32_t v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int32_t run = part[tid] - sum;
+    for (int b = lo; b < hi; ++b) {
+        group_off[b] = run;
+        run += (int32_t)((frame_off[b + 1] - frame_off[b] + 7) >> 3);
+    }
+    if (tid == 1023) group_off[n_utt] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void f512_group_fill_kernel(const int32_t* __restrict__ group_off, int32_t n_utt,
+                                                              int32_t* __restrict__ group_utt) {
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < n_utt; b += gridDim.x * blockDim.x)
+        for (int g = group_off[b]; g < group_off[b + 1]; ++g) group_utt[g] = b;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -459,7 +520,7 @@ static inline int fast512_plan_init(dsp_plan* p, const dsp_plan_desc* d, const i
     const int M = d->nfilt, C = d->numcep, L = d->frame_len;
     const int ni_real = (M + 7) / 8, nrows = (L + 15) / 16;
     int variant, NI;  // template instantiation: <NROWS, NI, NC>
-    const int nstage = ((7 * d->frame_step + L + 3) / 4 + 63) / 64;
+    const int nstage = ((7 * d->frame_step + L + 3) / 4 + 1 + 63) / 64;  // +1: ragged batches stage from an aligned start
     if (nrows <= 25 && ni_real <= 4 && C <= 13 && nstage <= 6) { variant = 0; NI = 4; }
     else if (nrows <= 25 && ni_real <= 5 && C <= 13 && nstage <= 6) { variant = 1; NI = 5; }
     else { variant = 2; NI = F512_MAX_NI; }
@@ -557,58 +618,77 @@ static inline void fast512_plan_free(dsp_plan* p) {
     p->d_fast = nullptr;
 }
 
-// uniform batches whose utterances start 16-byte aligned (int16: 8-byte) take the fast path
+// The fast kernel serves (a) dense batches with N % 4 == 0 and (b) ragged batches (any lengths and
+// offsets); the buffer itself must start 16-byte aligned (8 for int16) either way.
 static inline bool fast512_applicable(const dsp_plan* p, const BatchGeom& bg, const void* d_wave, int dtype) {
     if (!p->d_fast) return false;
-    if (bg.uniform_samples <= 0 || (bg.uniform_samples % 4) != 0) return false;
-    if (bg.uniform_samples > 0x3fffffff || ((bg.uniform_frames + 7) / 8) * bg.n_utt > 0x3fffffff) return false;  // 32-bit indexing
     const uintptr_t a = reinterpret_cast<uintptr_t>(d_wave);
-    return (a % (dtype == DSP_WAVE_I16 ? 8 : 16)) == 0;
+    if ((a % (dtype == DSP_WAVE_I16 ? 8 : 16)) != 0) return false;
+    if (bg.uniform_samples > 0) {
+        if ((bg.uniform_samples % 4) != 0) return false;
+        return bg.uniform_samples <= 0x3fffffff && ((bg.uniform_frames + 7) / 8) * bg.n_utt <= 0x3fffffff;  // 32-bit indexing
+    }
+    return bg.total_frames / 8 + bg.n_utt <= 0x3fffffff;
 }
 
-
-template <int NROWS, int NI, int NC, int NSTAGE>
-static int fast512_launch_t(const Fast512Plan* fp, const F512Params& P, const void* d_wave, int dtype,
-                            const BatchGeom& bg, float* d_out, int64_t ld_out, hipStream_t st) {
+template <int NROWS, int NI, int NC, int NSTAGE, int DTYPE, bool RAGGED>
+static int fast512_launch_k(const F512Params& P, const void* d_wave, const BatchGeom& bg, float* d_out,
+                            int64_t ld_out, int64_t groups_bound, hipStream_t st) {
     const size_t lds = ((size_t)P.tab_floats + (size_t)F512_WAVES * F512_WAVE_FLOATS) * sizeof(float);
     // balanced persistent grid: every wave runs the same number of groups (no ragged last round)
     const int64_t cap = 256 * (16 / F512_WAVES);  // 256 CUs x resident workgroups (<= 16 waves per CU)
-    int64_t blocks = (P.total_groups + F512_WAVES - 1) / F512_WAVES;
+    int64_t blocks = (groups_bound + F512_WAVES - 1) / F512_WAVES;
     if (blocks > cap) {
         const int64_t rounds = (blocks + cap - 1) / cap;
         blocks = (blocks + rounds - 1) / rounds;
     }
-    hipError_t e;
-    if (dtype == DSP_WAVE_I16) {
-        auto k = mfcc512_kernel<NROWS, NI, NC, NSTAGE, DSP_WAVE_I16, F512_WAVES>;
-        static size_t lds_set = 0;  // raise the dynamic-LDS limit once per instantiation (and on growth)
-        if (lds > lds_set) {
-            e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return DSP_EHIP;
-            lds_set = lds;
-        }
-        k<<<(int)blocks, 64 * F512_WAVES, lds, st>>>(P, bg, d_wave, d_out, ld_out);
-    } else {
-        auto k = mfcc512_kernel<NROWS, NI, NC, NSTAGE, DSP_WAVE_F32, F512_WAVES>;
-        static size_t lds_set = 0;
-        if (lds > lds_set) {
-            e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return DSP_EHIP;
-            lds_set = lds;
-        }
-        k<<<(int)blocks, 64 * F512_WAVES, lds, st>>>(P, bg, d_wave, d_out, ld_out);
+    auto k = mfcc512_kernel<NROWS, NI, NC, NSTAGE, DTYPE, F512_WAVES, RAGGED>;
+    static size_t lds_set = 0;  // raise the dynamic-LDS limit once per instantiation (and on growth)
+    if (lds > lds_set) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return DSP_EHIP;
+        lds_set = lds;
     }
+    k<<<(int)blocks, 64 * F512_WAVES, lds, st>>>(P, bg, d_wave, d_out, ld_out);
     return hipGetLastError() == hipSuccess ? DSP_OK : DSP_EHIP;
+}
+
+template <int NROWS, int NI, int NC, int NSTAGE>
+static int fast512_launch_t(F512Params P, const void* d_wave, int dtype, const BatchGeom& bg, float* d_out,
+                            int64_t ld_out, hipStream_t st) {
+    if (bg.uniform_samples > 0) {
+        P.groups_per_utt = (bg.uniform_frames + 7) / 8;
+        P.total_groups = P.groups_per_utt * bg.n_utt;
+        if (dtype == DSP_WAVE_I16)
+            return fast512_launch_k<NROWS, NI, NC, NSTAGE, DSP_WAVE_I16, false>(P, d_wave, bg, d_out, ld_out, P.total_groups, st);
+        return fast512_launch_k<NROWS, NI, NC, NSTAGE, DSP_WAVE_F32, false>(P, d_wave, bg, d_out, ld_out, P.total_groups, st);
+    }
+    // ragged: build the group tables in a stream-ordered scratch allocation (no host sync)
+    const int64_t bound = bg.total_frames / 8 + bg.n_utt;  // >= sum ceil(T_b / 8)
+    int32_t* ws = nullptr;
+    const size_t ws_bytes = ((size_t)bg.n_utt + 1 + (size_t)bound) * sizeof(int32_t);
+    if (hipMallocAsync(reinterpret_cast<void**>(&ws), ws_bytes, st) != hipSuccess) return DSP_EHIP;
+    int32_t* group_off = ws;
+    int32_t* group_utt = ws + bg.n_utt + 1;
+    f512_group_prefix_kernel<<<1, 1024, 0, st>>>(bg.frame_off, bg.n_utt, group_off);
+    const int fill_blocks = (int)((bg.n_utt + 255) / 256 < 1024 ? (bg.n_utt + 255) / 256 : 1024);
+    f512_group_fill_kernel<<<fill_blocks, 256, 0, st>>>(group_off, bg.n_utt, group_utt);
+    P.group_off = group_off;
+    P.group_utt = group_utt;
+    int rc;
+    if (dtype == DSP_WAVE_I16)
+        rc = fast512_launch_k<NROWS, NI, NC, NSTAGE, DSP_WAVE_I16, true>(P, d_wave, bg, d_out, ld_out, bound, st);
+    else
+        rc = fast512_launch_k<NROWS, NI, NC, NSTAGE, DSP_WAVE_F32, true>(P, d_wave, bg, d_out, ld_out, bound, st);
+    if (hipFreeAsync(ws, st) != hipSuccess && rc == DSP_OK) rc = DSP_EHIP;
+    return rc;
 }
 
 static inline int fast512_launch(const dsp_plan* p, const void* d_wave, int dtype, const BatchGeom& bg,
                                  float* d_out, int64_t ld_out, hipStream_t st) {
     const Fast512Plan* fp = static_cast<const Fast512Plan*>(p->d_fast);
-    F512Params P = fp->P;
-    P.groups_per_utt = (bg.uniform_frames + 7) / 8;
-    P.total_groups = P.groups_per_utt * bg.n_utt;
     // exact instantiations for the common shapes, a padded catch-all otherwise (chosen at plan init)
-    if (fp->variant == 0) return fast512_launch_t<25, 4, 13, 6>(fp, P, d_wave, dtype, bg, d_out, ld_out, st);
-    if (fp->variant == 1) return fast512_launch_t<25, 5, 13, 6>(fp, P, d_wave, dtype, bg, d_out, ld_out, st);
-    return fast512_launch_t<32, 8, 16, 9>(fp, P, d_wave, dtype, bg, d_out, ld_out, st);
+    if (fp->variant == 0) return fast512_launch_t<25, 4, 13, 6>(fp->P, d_wave, dtype, bg, d_out, ld_out, st);
+    if (fp->variant == 1) return fast512_launch_t<25, 5, 13, 6>(fp->P, d_wave, dtype, bg, d_out, ld_out, st);
+    return fast512_launch_t<32, 8, 16, 9>(fp->P, d_wave, dtype, bg, d_out, ld_out, st);
 }

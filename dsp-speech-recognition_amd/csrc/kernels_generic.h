@@ -232,6 +232,32 @@ __global__ __launch_bounds__(256) void delta_kernel(const float* __restrict__ in
 // numpy.pad(mode='edge') in base.py:75) go to LDS once; delta is formed in LDS for tile + halo N,
 // delta-delta from that, so every input value is read from HBM/L2 once instead of (2N+1)^2 times.
 #define DT_TILE 128
+// tile_off[b] = sum_{i<b} ceil(T_i / 2^shift), tile_off[n] = total (single block).
+__global__ __launch_bounds__(1024) void prefix_ceil_kernel(const int64_t* __restrict__ frame_off, int32_t n_utt,
+                                                           int shift, int64_t* __restrict__ tile_off) {
+    __shared__ int64_t part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n_utt + 1023) / 1024;
+    const int lo = tid * per, hi = min(lo + per, n_utt);
+    const int64_t rnd = ((int64_t)1 << shift) - 1;
+    int64_t sum = 0;
+    for (int b = lo; b < hi; ++b) sum += (frame_off[b + 1] - frame_off[b] + rnd) >> shift;
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int64_t v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int64_t run = part[tid] - sum;
+    for (int b = lo; b < hi; ++b) {
+        tile_off[b] = run;
+        run += (frame_off[b + 1] - frame_off[b] + rnd) >> shift;
+    }
+    if (tid == 1023) tile_off[n_utt] = part[1023];
+}
+
 template <int DC>  // DC > 0: feature width known at compile time (division by a constant); 0: runtime D
 __global__ __launch_bounds__(256) void delta_tiled_kernel(const float* __restrict__ in, int64_t ld_in, BatchGeom bg,
                                                           int32_t D_rt, int32_t N, float inv_den,
@@ -250,6 +276,7 @@ __global__ __launch_bounds__(256) void delta_tiled_kernel(const float* __restric
         base = (int64_t)u * bg.uniform_frames;
         T = (int)bg.uniform_frames;
     } else {
+        if ((int64_t)blockIdx.x >= tile_off[bg.n_utt]) return;  // grid is sized by an upper bound
         const int32_t u = dsp_find_utt(tile_off, bg.n_utt, (int64_t)blockIdx.x);
         tile = (int32_t)(blockIdx.x - tile_off[u]);
         base = bg.frame_off[u];

@@ -46,6 +46,8 @@ SIGNATURES = {
     'dsp_frame_offsets': (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp]),
     'dsp_plan_create': (C.c_int, [C.POINTER(PlanDesc), C.POINTER(c_vp)]),
     'dsp_plan_destroy': (C.c_int, [c_vp]),
+    'dsp_plan_has_fast_path': (C.c_int, [c_vp]),
+    'dsp_debug_force_generic': (C.c_int, [C.c_int]),
     'dsp_preemphasis_batch': (C.c_int, [c_vp, C.c_int, c_vp, c_i32, c_i64, c_f32, c_vp, c_vp]),
     'dsp_features_batch': (C.c_int, [c_vp, c_vp, C.c_int, c_vp, c_vp, c_i32, c_i64, c_i64, C.c_int,
                                      c_vp, c_i64, c_vp, c_vp]),
