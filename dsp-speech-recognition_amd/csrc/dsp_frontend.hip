@@ -417,6 +417,22 @@ int dsp_vad_features_batch(const void* d_wave, int wave_dtype, const int64_t* d_
     return DSP_OK;
 }
 
+int dsp_trim_scale_batch(const void* d_wave, int wave_dtype, const int64_t* d_sample_offsets,
+                         const int64_t* d_segments, const int64_t* d_dst_offsets, int32_t n_utt,
+                         int32_t unit_variance, float* d_out, void* stream) {
+    if (!d_wave || !d_sample_offsets || !d_segments || !d_dst_offsets || !d_out || n_utt <= 0)
+        return fail(DSP_EINVAL, "dsp_trim_scale_batch: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (wave_dtype == DSP_WAVE_I16)
+        trim_scale_kernel<DSP_WAVE_I16><<<n_utt, 256, 0, st>>>(d_wave, d_sample_offsets, d_segments, d_dst_offsets, unit_variance, d_out);
+    else if (wave_dtype == DSP_WAVE_F32)
+        trim_scale_kernel<DSP_WAVE_F32><<<n_utt, 256, 0, st>>>(d_wave, d_sample_offsets, d_segments, d_dst_offsets, unit_variance, d_out);
+    else
+        return fail(DSP_EINVAL, "unsupported wave_dtype %d", wave_dtype);
+    HIP_TRY(hipGetLastError());
+    return DSP_OK;
+}
+
 int dsp_endpoint_rule_batch(const double* d_amp_sum, const int32_t* d_zcr, const int64_t* d_frame_offsets,
                             int32_t n_utt, int32_t frame_len, double cfg_frame, double cfg_step,
                             int32_t* d_endpoints, void* stream) {

@@ -463,3 +463,42 @@ __global__ __launch_bounds__(64) void endpoint_rule_kernel(const double* __restr
     endpoints[2 * b] = (int32_t)j;
     endpoints[2 * b + 1] = (int32_t)k;
 }
+
+// Endpoint-trimmed copy of a ragged batch (model.py:52-64 without augmentation): utterance b keeps
+// samples [lo_b, hi_b) and is divided by its population standard deviation when `unit_variance`
+// (sklearn scale(with_mean=False), zero std -> 1).  One workgroup per utterance; fp64 statistics.
+template <int DTYPE>
+__global__ __launch_bounds__(256) void trim_scale_kernel(const void* __restrict__ wave, const int64_t* __restrict__ src_off,
+                                                         const int64_t* __restrict__ seg, const int64_t* __restrict__ dst_off,
+                                                         int32_t unit_variance, float* __restrict__ out) {
+    __shared__ double red[2][4];
+    const int b = blockIdx.x;
+    const int64_t s0 = src_off[b] + seg[2 * b];
+    const int64_t n = seg[2 * b + 1] - seg[2 * b];
+    float* dst = out + dst_off[b];
+    double inv = 1.0;
+    if (unit_variance && n > 0) {
+        double s = 0.0, q = 0.0;
+        for (int64_t i = threadIdx.x; i < n; i += 256) {
+            const double v = (double)dsp_load_sample<DTYPE>(wave, s0 + i);
+            s += v;
+            q += v * v;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s += __shfl_xor(s, o, 64);
+            q += __shfl_xor(q, o, 64);
+        }
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
+        __syncthreads();
+        s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const double mean = s / (double)n;
+        double var = q / (double)n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double sd = sqrt(var);
+        inv = sd > 0.0 ? 1.0 / sd : 1.0;
+    }
+    for (int64_t i = threadIdx.x; i < n; i += 256)
+        dst[i] = (float)((double)dsp_load_sample<DTYPE>(wave, s0 + i) * inv);
+}

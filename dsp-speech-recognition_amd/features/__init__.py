@@ -14,5 +14,6 @@ from .base import *  # noqa: F401,F403
 from .sigproc import *  # noqa: F401,F403
 from .endpoint import *  # noqa: F401,F403
 from .preprocess import *  # noqa: F401,F403
-from . import base, sigproc, endpoint, preprocess, batch  # noqa: F401
+from . import base, sigproc, endpoint, preprocess, batch, pipeline  # noqa: F401
 from .batch import FeaturePlan, EndpointPlan  # noqa: F401
+from .pipeline import VadMfccPipeline  # noqa: F401

@@ -171,6 +171,16 @@ int dsp_endpoint_rule_batch(const double* d_amp_sum, const int32_t* d_zcr,
                             const int64_t* d_frame_offsets, int32_t n_utt, int32_t frame_len,
                             double cfg_frame, double cfg_step, int32_t* d_endpoints, void* stream);
 
+/*
+ * Endpoint-trimmed copy (fp32 out): utterance b keeps samples [segments[2b], segments[2b+1]) relative
+ * to its start and lands at d_dst_offsets[b]; with unit_variance != 0 it is divided by its population
+ * standard deviation (zero -> 1), i.e. sig[left:right] -> sklearn scale(with_mean=False) as
+ * model.py:62-63 does before feature extraction.  fp64 statistics.
+ */
+int dsp_trim_scale_batch(const void* d_wave, int wave_dtype, const int64_t* d_sample_offsets,
+                         const int64_t* d_segments, const int64_t* d_dst_offsets, int32_t n_utt,
+                         int32_t unit_variance, float* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -141,3 +141,29 @@ def test_endpoint_batch_matches_single():
     for b, c in enumerate(clips):
         assert tuple(got[b]) == features.basic_endpoint_detection(c, 16000)
         assert tuple(got[b]) == dsp_oracle.basic_endpoint_detection(c, 16000)
+
+
+@pytest.mark.parametrize('unit_variance', [False, True])
+def test_config4_vad_trim_mfcc_pipeline(unit_variance):
+    """configs[3]: endpointing -> trim (-> unit variance, model.py:63) -> MFCC+delta+delta2 with
+    variable-length outputs, against the oracle run utterance by utterance."""
+    from features.pipeline import VadMfccPipeline
+    from golden_cases import make_signal
+    clips = [make_signal(('vad', 200 + i, 16000 + 1700 * i)) for i in range(10)]
+    clips.append(make_signal(('int16', 77, 9000)))      # no burst: whole-clip fallback
+    clips.append(make_signal(('bursts', 78, 32000)))
+    so = np.concatenate([[0], np.cumsum([len(c) for c in clips])]).astype(np.int64)
+    pipe = VadMfccPipeline(rate=16000, unit_variance=unit_variance, winfunc=np.hamming,
+                           **{k: v for k, v in CFG.items() if k != 'samplerate'})
+    out, fo, ends = pipe.run(np.concatenate(clips), so, delta_n=2)
+    assert fo[-1] == out.shape[0] and out.shape[1] == 39
+    for b, c in enumerate(clips):
+        lo, hi = dsp_oracle.basic_endpoint_detection(c, 16000)
+        assert (lo, hi) == (int(ends[b, 0]), int(ends[b, 1])) or (lo, min(hi, len(c))) == tuple(ends[b])
+        seg = np.asarray(c[lo:hi], dtype=np.float64)
+        if unit_variance:
+            seg = dsp_oracle.model_endpoint_scale(c, lo, hi).reshape(-1)
+        ref = dsp_oracle.mfcc_delta(seg, delta_n=2, winfunc=np.hamming, **CFG)
+        got = out[fo[b]:fo[b + 1]]
+        assert got.shape == ref.shape, (b, got.shape, ref.shape)
+        assert normwise(got, ref) <= TOL, (b, normwise(got, ref))
