@@ -50,3 +50,19 @@ def model_pipeline(sig, rate):
     """Raw int16 clip -> ((mfcc0, mfcc1, mfcc2), n) exactly as RNNModel.get_batch_full feeds the
     classifier per utterance (model.py:113-124, augment=False)."""
     return feature_extract_mfcc(endpoint_detect(sig, rate), rate)
+
+
+def batch_to_rnn_input(features, frame_offsets, max_len=200):
+    """[sum T_b, D] device (torch) features + frame offsets -> ([max_len, B, D], len0) exactly as
+    model.py:35-50,131-135 lays a batch out for the classifiers (`inp[T, B, 39]`, zero padded or
+    truncated to 200 frames).  Stays on the device: no host round trip between the HIP front-end and
+    the PyTorch-ROCm RNN."""
+    import torch
+    fo = torch.as_tensor(np.asarray(frame_offsets), device=features.device)
+    B = fo.numel() - 1
+    lens = (fo[1:] - fo[:-1]).clamp(max=max_len)
+    t = torch.arange(max_len, device=features.device)[:, None]            # [max_len, 1]
+    src = (fo[:-1][None, :] + t).clamp(max=features.shape[0] - 1)          # [max_len, B]
+    inp = features[src]                                                     # [max_len, B, D]
+    inp = inp * (t < lens[None, :]).unsqueeze(-1).to(features.dtype)
+    return inp, lens.cpu().numpy()

@@ -1,0 +1,67 @@
+"""Next-row f-3: the GPU front-end feeds a PyTorch-ROCm recurrent classifier without a
+host round trip.  The reference ships no weights or data, so the check is logits parity on seeded
+random weights: the same classifier fed (a) features from the HIP kernels, resident on the device,
+and (b) features from the fp64 oracle."""
+import numpy as np
+import pytest
+
+from oracle import dsp_oracle
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(samplerate=16000, winlen=0.025, winstep=0.01, numcep=13, nfilt=40, nfft=512, lowfreq=0,
+           highfreq=None, preemph=0.97, ceplifter=22, appendEnergy=True)
+
+
+def _classifier(torch):
+    """Same shape as the reference's vanilla `RNN` head (rnn_clf.py:12-34): bidirectional GRU over
+    [T, B, 39], directions summed, average + max pooling over time, Linear(2H -> 20)."""
+    class Clf(torch.nn.Module):
+        def __init__(self, d=39, h=200, classes=20):
+            super().__init__()
+            self.gru = torch.nn.GRU(d, h, bidirectional=True)
+            self.out = torch.nn.Linear(2 * h, classes)
+            self.h = h
+
+        def forward(self, inp, lens):
+            y, _ = self.gru(inp)                                   # [T, B, 2H]
+            y = y[..., :self.h] + y[..., self.h:]
+            mask = (torch.arange(inp.shape[0], device=inp.device)[:, None] < lens[None, :]).unsqueeze(-1)
+            avg = (y * mask).sum(0) / lens[:, None]
+            mx = y.masked_fill(~mask, -1e30).max(0).values
+            return self.out(torch.cat([avg, mx], dim=1))
+    return Clf()
+
+
+def test_device_features_feed_torch_rnn():
+    import torch
+    from features.batch import FeaturePlan
+    from features.model_glue import batch_to_rnn_input
+    dev = torch.device('cuda', 0)
+    rng = np.random.default_rng(21)
+    lens = [16000, 12000, 20000, 8000, 16000, 30000, 40000, 9000]
+    so = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+    flat = (0.25 * rng.standard_normal(so[-1])).astype(np.float32)
+    plan = FeaturePlan(winfunc=np.hamming, **CFG)
+    waves_dev = torch.from_numpy(flat).to(dev)
+    feats, fo = plan.mfcc_batch(waves_dev, sample_offsets=so, delta_n=2)      # stays on the device
+    assert feats.is_cuda and feats.shape == (fo[-1], 39)
+    inp, len0 = batch_to_rnn_input(feats, fo, 200)
+    assert inp.shape == (200, len(lens), 39) and inp.is_cuda
+    ref_rows = [dsp_oracle.mfcc_delta(flat[so[b]:so[b + 1]].astype(np.float64), delta_n=2, winfunc=np.hamming, **CFG)
+                for b in range(len(lens))]
+    ref_inp = np.zeros((200, len(lens), 39), dtype=np.float32)
+    for b, r in enumerate(ref_rows):
+        n = min(len(r), 200)
+        ref_inp[:n, b] = r[:n]
+        assert len0[b] == n
+    assert np.max(np.abs(inp.cpu().numpy() - ref_inp)) <= 1e-4 * np.max(np.abs(ref_inp))
+    torch.manual_seed(0)
+    clf = _classifier(torch).to(dev).eval()
+    lens_t = torch.as_tensor(len0, device=dev)
+    with torch.no_grad():
+        logits_gpu = clf(inp, lens_t).cpu().numpy()
+        logits_ref = clf(torch.from_numpy(ref_inp).to(dev), lens_t).cpu().numpy()
+    assert logits_gpu.shape == (len(lens), 20)
+    assert np.max(np.abs(logits_gpu - logits_ref)) <= 1e-3 * max(1.0, np.max(np.abs(logits_ref)))
+    assert np.array_equal(logits_gpu.argmax(1), logits_ref.argmax(1))
