@@ -19,6 +19,7 @@
 #pragma once
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "dsp_common.h"
@@ -69,32 +70,54 @@ __device__ __forceinline__ float frame_allreduce(float v) {
 #define F512_FENCE() asm volatile("" ::: "memory")
 
 typedef float f512_v2 __attribute__((ext_vector_type(2)));
-// Plain ds_read_b64 (2 LDS cycles per wave, 64-bank addressing).  hipcc would pair neighbouring
-// b64 reads into ds_read2_b64, which costs 8 cycles and uses 32-bank addressing -- with frames
-// 160 floats apart that is a 2-way conflict on top.  The caller waits with F512_LDS_WAIT().
-template <int OFF_BYTES>
-__device__ __forceinline__ f512_v2 f512_lds_read_b64(uint32_t addr) {
-    f512_v2 v;
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF_BYTES));
-    return v;
-}
-// hipcc may hoist register-only arithmetic above an asm wait ("memory" does not order it):
-// the sched_barrier pins everything that follows behind the wait.
-#define F512_LDS_WAIT()                                   \
-    do {                                                  \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-        __builtin_amdgcn_sched_barrier(0);                \
-    } while (0)
+// Pass-1 reads are plain ds_read_b64 (2 LDS cycles per wave, 64-bank addressing) issued from inline
+// asm: hipcc would pair neighbouring b64 reads into ds_read2_b64, which costs 8 cycles and uses
+// 32-bank addressing -- with frames 160 floats apart that is a 2-way conflict on top.
 __device__ __forceinline__ uint32_t f512_lds_addr(const void* p) {
     return static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p));
 }
 
-template <int N, int R, int ROW0>
-__device__ __forceinline__ void f512_load_rows(uint32_t fr, uint32_t wn, f512_v2 (&xv)[N], f512_v2 (&wv)[N]) {
-    if constexpr (R < N) {  // rows ROW0 .. ROW0 + N - 1, 64 bytes apart
-        xv[R] = f512_lds_read_b64<64 * (ROW0 + R)>(fr);
-        wv[R] = f512_lds_read_b64<64 * (ROW0 + R)>(wn);
-        f512_load_rows<N, R + 1, ROW0>(fr, wn, xv, wv);
+// Rows ROW0 .. ROW0+7 of the frame's column pair and of the window: 16 plain ds_read_b64 and their
+// wait in ONE asm statement, so the outputs are really valid where the compiler believes they are.
+// (With the wait in a separate statement hipcc may spill or move a destination register before
+// its data has arrived -- seen once register pressure forced spills in the 32-row instantiation.)
+template <int ROW0>
+__device__ __forceinline__ void f512_load_rows8(uint32_t fr, uint32_t wn, f512_v2 (&xv)[8], f512_v2 (&wv)[8]) {
+    asm volatile(
+        "ds_read_b64 %0, %16 offset:%18\n\tds_read_b64 %8, %17 offset:%18\n\t"
+        "ds_read_b64 %1, %16 offset:%19\n\tds_read_b64 %9, %17 offset:%19\n\t"
+        "ds_read_b64 %2, %16 offset:%20\n\tds_read_b64 %10, %17 offset:%20\n\t"
+        "ds_read_b64 %3, %16 offset:%21\n\tds_read_b64 %11, %17 offset:%21\n\t"
+        "ds_read_b64 %4, %16 offset:%22\n\tds_read_b64 %12, %17 offset:%22\n\t"
+        "ds_read_b64 %5, %16 offset:%23\n\tds_read_b64 %13, %17 offset:%23\n\t"
+        "ds_read_b64 %6, %16 offset:%24\n\tds_read_b64 %14, %17 offset:%24\n\t"
+        "ds_read_b64 %7, %16 offset:%25\n\tds_read_b64 %15, %17 offset:%25\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(xv[0]), "=&v"(xv[1]), "=&v"(xv[2]), "=&v"(xv[3]), "=&v"(xv[4]), "=&v"(xv[5]), "=&v"(xv[6]), "=&v"(xv[7]),
+          "=&v"(wv[0]), "=&v"(wv[1]), "=&v"(wv[2]), "=&v"(wv[3]), "=&v"(wv[4]), "=&v"(wv[5]), "=&v"(wv[6]), "=&v"(wv[7])
+        : "v"(fr), "v"(wn), "n"(64 * (ROW0 + 0)), "n"(64 * (ROW0 + 1)), "n"(64 * (ROW0 + 2)), "n"(64 * (ROW0 + 3)),
+          "n"(64 * (ROW0 + 4)), "n"(64 * (ROW0 + 5)), "n"(64 * (ROW0 + 6)), "n"(64 * (ROW0 + 7))
+        : "memory");
+}
+template <int ROW0>
+__device__ __forceinline__ void f512_load_rows1(uint32_t fr, uint32_t wn, f512_v2& xv, f512_v2& wv) {
+    asm volatile("ds_read_b64 %0, %2 offset:%4\n\tds_read_b64 %1, %3 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(xv), "=&v"(wv) : "v"(fr), "v"(wn), "n"(64 * ROW0) : "memory");
+}
+// z[ROW0 ..] = x * w for rows ROW0 .. NROWS-1, eight at a time
+template <int NROWS, int ROW0>
+__device__ __forceinline__ void f512_window_rows(uint32_t fr, uint32_t wn, cpx (&z)[32]) {
+    if constexpr (ROW0 + 8 <= NROWS) {
+        f512_v2 xv[8], wv[8];
+        f512_load_rows8<ROW0>(fr, wn, xv, wv);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) z[ROW0 + r] = {xv[r].x * wv[r].x, xv[r].y * wv[r].y};
+        f512_window_rows<NROWS, ROW0 + 8>(fr, wn, z);
+    } else if constexpr (ROW0 < NROWS) {
+        f512_v2 xv, wv;
+        f512_load_rows1<ROW0>(fr, wn, xv, wv);
+        z[ROW0] = {xv.x * wv.x, xv.y * wv.y};
+        f512_window_rows<NROWS, ROW0 + 1>(fr, wn, z);
     }
 }
 
@@ -252,22 +275,7 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
                     z[n1] = {frp[16 * n1] * wv.x, frp[16 * n1 + 1] * wv.y};
                 }
             } else {
-                // two batches of rows: all reads of a batch are in flight before its first multiply
-                constexpr int H = (NROWS + 1) / 2;
-                {
-                    f512_v2 xv[H], wv[H];
-                    f512_load_rows<H, 0, 0>(fr, wn, xv, wv);
-                    F512_LDS_WAIT();
-#pragma unroll
-                    for (int n1 = 0; n1 < H; ++n1) z[n1] = {xv[n1].x * wv[n1].x, xv[n1].y * wv[n1].y};
-                }
-                {
-                    f512_v2 xv[NROWS - H], wv[NROWS - H];
-                    f512_load_rows<NROWS - H, 0, H>(fr, wn, xv, wv);
-                    F512_LDS_WAIT();
-#pragma unroll
-                    for (int n1 = H; n1 < NROWS; ++n1) z[n1] = {xv[n1 - H].x * wv[n1 - H].x, xv[n1 - H].y * wv[n1 - H].y};
-                }
+                f512_window_rows<NROWS, 0>(fr, wn, z);
             }
 #pragma unroll
             for (int n1 = NROWS; n1 < 32; ++n1) z[n1] = {0.f, 0.f};
@@ -524,6 +532,9 @@ static inline int fast512_plan_init(dsp_plan* p, const dsp_plan_desc* d, const i
     if (nrows <= 25 && ni_real <= 4 && C <= 13 && nstage <= 6) { variant = 0; NI = 4; }
     else if (nrows <= 25 && ni_real <= 5 && C <= 13 && nstage <= 6) { variant = 1; NI = 5; }
     else { variant = 2; NI = F512_MAX_NI; }
+    if (const char* fv = getenv("DSP_F512_FORCE_CATCHALL")) {  // debugging aid: run any plan on the catch-all instantiation
+        if (fv[0] == '1') { variant = 2; NI = F512_MAX_NI; }
+    }
     std::vector<float> win(512, 0.f);
     for (int n = 0; n < L; ++n) win[n] = d->h_window[n];
     std::vector<float> tw1(15 * 8 * 4);

@@ -167,3 +167,50 @@ def test_config4_vad_trim_mfcc_pipeline(unit_variance):
         got = out[fo[b]:fo[b + 1]]
         assert got.shape == ref.shape, (b, got.shape, ref.shape)
         assert normwise(got, ref) <= TOL, (b, normwise(got, ref))
+
+
+@pytest.mark.parametrize('cfg', [
+    dict(winlen=0.03, winstep=0.01, nfilt=48, numcep=16),      # L=480 -> 30 rows, 6 mel groups: catch-all kernel
+    dict(winlen=0.032, winstep=0.008, nfilt=64, numcep=13),    # L=512 (= NFFT), S=128, 8 mel groups
+    dict(winlen=0.02, winstep=0.005, nfilt=26, numcep=12),     # L=320, S=80: 26-filter instantiation
+    dict(winlen=0.025, winstep=0.0101, nfilt=40, numcep=13),   # S=162 (even, not /4)
+    dict(winlen=0.025, winstep=0.01, nfilt=40, numcep=13, lowfreq=300, highfreq=3400, preemph=0.0),
+], ids=['L480_M48_C16', 'L512_M64', 'L320_M26_C12', 'S162', 'band_nopre'])
+@pytest.mark.parametrize('dtype', [np.float32, np.int16])
+def test_fast_kernel_instantiations(cfg, dtype):
+    """Every <rows, mel groups, cepstra> instantiation of the specialised kernel, dense and ragged,
+    fp32 and int16, against the oracle."""
+    from features.batch import FeaturePlan
+    from features import _native as nat
+    full = dict(samplerate=16000, nfft=512, lowfreq=0, highfreq=None, preemph=0.97, ceplifter=22, appendEnergy=True)
+    full.update(cfg)
+    plan = FeaturePlan(winfunc=np.hamming, **full)
+    assert nat.load().dsp_plan_has_fast_path(plan.plan.handle) == 1
+    # 64 filters on a 257-bin spectrum: the lowest ones are 1-2 bins wide and their logs amplify the
+    # fp32 FFT noise floor (the generic kernel shows 5.5e-5 on the same data)
+    tol = 3e-4 if full['nfilt'] >= 64 else TOL
+    dense = _batch(51, 24, 8000, dtype=dtype)
+    out, fo = plan.mfcc_batch(dense, delta_n=2)
+    lens = [8000, 513, 4097, 1, 7999, 12001, 640]
+    so = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+    flat = _batch(52, 1, int(so[-1]), dtype=dtype)[0]
+    out_r, fo_r = plan.mfcc_batch(flat, sample_offsets=so, delta_n=2)
+    for b in range(24):
+        ref = dsp_oracle.mfcc_delta(dense[b].astype(np.float64), delta_n=2, winfunc=np.hamming, **full)
+        assert normwise(out[fo[b]:fo[b + 1]], ref) <= tol, ('dense', b)
+    for b in range(len(lens)):
+        ref = dsp_oracle.mfcc_delta(flat[so[b]:so[b + 1]].astype(np.float64), delta_n=2, winfunc=np.hamming, **full)
+        assert out_r[fo_r[b]:fo_r[b + 1]].shape == ref.shape
+        assert normwise(out_r[fo_r[b]:fo_r[b + 1]], ref) <= tol, ('ragged', b, lens[b])
+
+
+def test_odd_hop_uses_generic_kernel_and_matches():
+    from features.batch import FeaturePlan
+    from features import _native as nat
+    full = dict(samplerate=16000, nfft=512, winlen=0.025, winstep=161 / 16000.0, nfilt=40, numcep=13)
+    plan = FeaturePlan(winfunc=np.hamming, **full)
+    assert nat.load().dsp_plan_has_fast_path(plan.plan.handle) == 0      # S = 161 is odd
+    x = _batch(53, 3, 8000)
+    out, fo = plan.mfcc_batch(x, delta_n=1)
+    ref = dsp_oracle.mfcc_delta(x[1].astype(np.float64), delta_n=1, winfunc=np.hamming, **full)
+    assert normwise(out[fo[1]:fo[2]], ref) <= TOL
