@@ -408,6 +408,10 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
             if (c == 0) {
 #pragma unroll
                 for (int m = 0; m < 8; ++m) ps[32 * m + 16] = podd[m];
+            } else {
+                // row padding 257..263: zero-weight mel taps may read it, so it must hold finite values
+                // (nothing else ever writes these slots in the last frame's row)
+                ps[256 + c] = 0.f;
             }
         }
         F512_FENCE();
