@@ -532,7 +532,10 @@ static inline int fast512_plan_init(dsp_plan* p, const dsp_plan_desc* d, const i
     const int M = d->nfilt, C = d->numcep, L = d->frame_len;
     const int ni_real = (M + 7) / 8, nrows = (L + 15) / 16;
     int variant, NI;  // template instantiation: <NROWS, NI, NC>
-    const int nstage = ((7 * d->frame_step + L + 3) / 4 + 1 + 63) / 64;  // +1: ragged batches stage from an aligned start
+    // The wave stages every sample its pass-1 rows will touch (16 x NROWS per frame, window zero beyond
+    // L), so no multiply ever sees stale LDS.  +1 vector: ragged batches stage from an aligned start.
+    const int span25 = 7 * d->frame_step + 400, span32 = 7 * d->frame_step + 512;
+    const int nstage = ((span25 + 3) / 4 + 1 + 63) / 64;
     if (nrows <= 25 && ni_real <= 4 && C <= 13 && nstage <= 6) { variant = 0; NI = 4; }
     else if (nrows <= 25 && ni_real <= 5 && C <= 13 && nstage <= 6) { variant = 1; NI = 5; }
     else { variant = 2; NI = F512_MAX_NI; }
@@ -619,7 +622,7 @@ static inline int fast512_plan_init(dsp_plan* p, const dsp_plan_desc* d, const i
     fp->P.L = L; fp->P.S = d->frame_step; fp->P.M = M; fp->P.C = C;
     fp->P.append_energy = d->append_energy ? 1 : 0;
     fp->P.preemph = d->preemph;
-    fp->P.span_vec = (7 * d->frame_step + L + 3) / 4;
+    fp->P.span_vec = ((variant == 2 ? span32 : span25) + 3) / 4;
     fp->variant = variant;
     p->d_fast = fp;
     return DSP_OK;
