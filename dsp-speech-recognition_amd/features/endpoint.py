@@ -145,3 +145,19 @@ def basic_endpoint_detection(sig, rate, return_feature=False):
     amp = [a for a in d_amp.download((T,), np.float64) / L]
     zcr = [np.int64(z) for z in d_zcr.download((T,), np.int32)]
     return lo, hi, amp, zcr
+
+
+def robust_endpoint_detection(sig, rate):
+    """Autocorrelation-gated variant (endpoint.py:68-92): one amplitude-rule pass with mh = 0.5 that
+    only grows a segment over frames whose normalised autocorrelation peak (lags rate/500..rate/50)
+    exceeds 0.55.  Frames, amplitude and ZCR come from the GPU; the gate is evaluated in fp64 on the
+    handful of frames the rule actually visits (scalar control flow, as in the reference)."""
+    frames = to_frames(sig, rate, cfg.frame, step=cfg.step)
+    amp = get_amplitude(frames)
+    seg = amplitude_rule(amp, 0.5, frames=frames, use_acr=True, rate=rate)
+    left, right = seg[0][0], seg[-1][1]
+    zcr = get_zcr(frames)
+    left2, right2 = zcr_rule(zcr, left, right)
+    if right2 - left2 < 50:
+        left2, right2 = 0, len(frames)
+    return int(left2 * cfg.step * rate), int(right2 * cfg.step * rate)

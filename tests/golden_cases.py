@@ -172,6 +172,11 @@ _add('zcr_alt', 'get_zcr', ('int16', 63, 3000), frame_len=480, frame_step=160)
 _add('amprule_bursts', 'amplitude_rule', ('bursts', 55, 32000), mh=0.25)
 _add('amprule_bursts_mh', 'amplitude_rule', ('bursts', 55, 32000), mh=0.125)
 
+# next-row f-4: autocorrelation-gated endpointing
+for i, spec in enumerate((('vad', 90, 25600), ('vad', 91, 32000), ('bursts', 92, 32000), ('int16', 93, 16000),
+                          ('vad', 94, 52920, 44100, 0.7))):
+    _add(f'robust_endpoint_{i}', 'robust_endpoint_detection', spec, rate=(spec[3] if len(spec) > 3 else 16000))
+
 # next-row f-1: model.py glue (endpoint_detect without augmentation, feature_extract_mfcc)
 _add('model_feat_44k', 'model_feature_extract_mfcc', ('vad', 70, 52920, 44100, 0.7), rate=44100)
 _add('model_feat_48k', 'model_feature_extract_mfcc', ('vad', 71, 60000, 48000, 0.6), rate=48000)
@@ -242,6 +247,9 @@ def run_case(case, api):
         lo, hi, amp, zcr = api.basic_endpoint_detection(x, kw['rate'], return_feature=True)
         return {'endpoints': np.array([lo, hi], dtype=np.int64), 'amp': np.asarray(amp, dtype=np.float64),
                 'zcr': np.asarray(zcr, dtype=np.int64)}
+    if fn == 'robust_endpoint_detection':
+        lo, hi = api.robust_endpoint_detection(x, kw['rate'])
+        return {'endpoints': np.array([lo, hi], dtype=np.int64)}
     if fn == 'amplitude_feature':
         return {'out': np.asarray(api.amplitude_feature(x, **kw), dtype=np.float64)}
     if fn == 'get_amplitude':

@@ -35,7 +35,8 @@ def api():
     a = Api()
     for name in ('preemphasis', 'framesig', 'to_frames', 'magspec', 'powspec', 'logpowspec', 'deframesig',
                  'get_filterbanks', 'fbank', 'mfcc', 'lifter', 'delta', 'get_amplitude', 'get_zcr',
-                 'amplitude_rule', 'zcr_rule', 'amplitude_feature', 'basic_endpoint_detection'):
+                 'amplitude_rule', 'zcr_rule', 'amplitude_feature', 'basic_endpoint_detection',
+                 'robust_endpoint_detection'):
         setattr(a, name, getattr(features, name))
     a.preemphasis = features.sigproc.preemphasis
     from features.model_glue import model_pipeline
