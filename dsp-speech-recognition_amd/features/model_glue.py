@@ -66,3 +66,49 @@ def batch_to_rnn_input(features, frame_offsets, max_len=200):
     inp = features[src]                                                     # [max_len, B, D]
     inp = inp * (t < lens[None, :]).unsqueeze(-1).to(features.dtype)
     return inp, lens.cpu().numpy()
+
+
+class ModelFeatureBatch:
+    """Batched, device-resident form of RNNModel.get_batch_full (model.py:113-135, augment=False):
+    endpointing -> trim -> unit variance -> MFCC on the (1, N) view (no pre-emphasis, sigproc.py:185)
+    -> minus the utterance's scalar mean -> delta(3), delta(delta, 3) -> z-score of the static
+    coefficients -> [200, B, 39] zero padded.  Kernels come from the C ABI; the per-utterance
+    reductions (one mean, 13 means / variances) are torch segment sums on the same device."""
+
+    def __init__(self, rate, frame=0.03, step=0.01, nfft=1536, delta_n=3, max_len=200):
+        from .pipeline import VadMfccPipeline
+        self.pipe = VadMfccPipeline(rate=rate, frame=frame, step=step, unit_variance=True, winlen=frame,
+                                    winstep=step, nfft=nfft, preemph=0.0, winfunc=np.hamming)
+        self.delta_n, self.max_len = delta_n, max_len
+
+    def run(self, waves, sample_offsets):
+        """-> (inp [max_len, B, 39] torch tensor on cuda:0, len0 [B], endpoints [B, 2])."""
+        import torch
+        from . import _native as nat
+        lib = nat.load()
+        m0, fo, ends = self.pipe.run(waves, sample_offsets, delta_n=0)       # [sum T, 13] host fp32
+        dev = torch.device('cuda', 0)
+        x = torch.from_numpy(m0).to(dev)
+        fo_t = torch.as_tensor(fo, device=dev)
+        lens = fo_t[1:] - fo_t[:-1]
+        B, C = lens.numel(), x.shape[1]
+        seg = torch.repeat_interleave(torch.arange(B, device=dev), lens)
+        # mfcc0 -= mean over the whole [T, 13] block of the utterance (model.py:75), in fp64
+        tot = torch.zeros(B, dtype=torch.float64, device=dev).index_add_(0, seg, x.double().sum(1))
+        x = (x.double() - (tot / (lens * C).double())[seg, None]).float().contiguous()
+        out = torch.empty((x.shape[0], 3 * C), dtype=torch.float32, device=dev)
+        out[:, :C] = x
+        d_fo = fo_t.contiguous()
+        st = torch.cuda.current_stream(dev).cuda_stream
+        nat.check(lib.dsp_delta_batch(out.data_ptr(), 3 * C, d_fo.data_ptr(), B, x.shape[0], 0, C, self.delta_n,
+                                      out.data_ptr() + 4 * C, 3 * C, out.data_ptr() + 8 * C, 3 * C, st))
+        # per-coefficient z-score of the static part only, AFTER the deltas were taken (model.py:78)
+        s1 = torch.zeros((B, C), dtype=torch.float64, device=dev).index_add_(0, seg, x.double())
+        mu = s1 / lens[:, None].double()
+        dlt = x.double() - mu[seg]
+        var = torch.zeros((B, C), dtype=torch.float64, device=dev).index_add_(0, seg, dlt * dlt) / lens[:, None].double()
+        sd = var.sqrt()
+        sd = torch.where(sd == 0, torch.ones_like(sd), sd)
+        out[:, :C] = (dlt / sd[seg]).float()
+        inp, len0 = batch_to_rnn_input(out, fo, self.max_len)
+        return inp, len0, ends

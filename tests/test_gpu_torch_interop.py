@@ -65,3 +65,34 @@ def test_device_features_feed_torch_rnn():
     assert logits_gpu.shape == (len(lens), 20)
     assert np.max(np.abs(logits_gpu - logits_ref)) <= 1e-3 * max(1.0, np.max(np.abs(logits_ref)))
     assert np.array_equal(logits_gpu.argmax(1), logits_ref.argmax(1))
+
+
+def test_model_feature_batch_matches_reference_pipeline(golden):
+    """Next-row f-1: the whole per-utterance glue of model.py (endpoint -> trim -> unit variance ->
+    MFCC nfft=1536 -> mean removal -> delta(3) x2 -> z-score -> pad 200), batched on the device,
+    against outputs of the REAL reference pipeline (golden) and the oracle."""
+    from features.model_glue import ModelFeatureBatch
+    from golden_cases import make_signal, case_by_name
+    from conftest import normwise
+    clips = [make_signal(case_by_name('model_feat_44k')['sig']),
+             make_signal(('vad', 72, 60000, 44100, 0.5)),
+             make_signal(('vad', 73, 47000, 44100, 0.8))]
+    so = np.concatenate(([0], np.cumsum([len(c) for c in clips]))).astype(np.int64)
+    inp, len0, ends = ModelFeatureBatch(rate=44100).run(np.concatenate(clips), so)
+    assert inp.shape == (200, 3, 39)
+    got = inp.cpu().numpy()
+    # utterance 0: the reference itself
+    for key, col in (('m0', 0), ('m1', 13), ('m2', 26)):
+        ref = golden[f'model_feat_44k/{key}']
+        n = min(len(ref), 200)
+        assert len0[0] == n == int(golden['model_feat_44k/len'][0])
+        tol = 2e-3 if key == 'm0' else 1e-4   # z-scoring divides by small per-coefficient spreads
+        assert normwise(got[:n, 0, col:col + 13], ref[:n]) <= tol, key
+        assert not got[n:, 0].any()
+    # utterances 1, 2: the oracle
+    for b in (1, 2):
+        (m0, m1, m2), n = dsp_oracle.model_pipeline(clips[b], 44100)
+        assert len0[b] == n
+        ref = np.concatenate([m0, m1, m2], axis=1)[:n]
+        assert normwise(got[:n, b, 13:], ref[:, 13:]) <= 1e-4
+        assert normwise(got[:n, b, :13], ref[:, :13]) <= 2e-3
