@@ -353,13 +353,14 @@ int dsp_delta_batch(const float* d_in, int64_t ld_in, const int64_t* d_frame_off
             delta_tiled_kernel<0><<<(int)blocks, 256, lds, (hipStream_t)stream>>>(
                 d_in, ld_in, bg, D, N, inv_den, d_out, ld_out, d_out_dd, ld_out_dd, (int32_t)tiles, nullptr);
     } else if (uniform_frames <= 0 && lds <= 64 * 1024 && ld_in <= 0x7fffff && ld_out <= 0x7fffff && ld_out_dd <= 0x7fffff) {
-        // ragged: per-utterance tile prefix in a stream-ordered scratch buffer, grid sized by a bound
+        // ragged: per-utterance tile prefix in a pooled, event-guarded workspace, grid sized by a bound
         static_assert(DT_TILE == 128, "shift below assumes 128-frame tiles");
         const int64_t bound = n_frames_total / DT_TILE + n_utt;
         if (bound > 0x7fffffff) return fail(DSP_EINVAL, "too many delta tiles");
-        int64_t* tile_off = nullptr;
         hipStream_t st = (hipStream_t)stream;
-        HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&tile_off), ((size_t)n_utt + 1) * sizeof(int64_t), st));
+        DspWorkspace* w = dsp_workspace_pool().acquire(((size_t)n_utt + 1) * sizeof(int64_t));
+        if (!w) return fail(DSP_EHIP, "workspace allocation failed");
+        int64_t* tile_off = static_cast<int64_t*>(w->ptr);
         prefix_ceil_kernel<<<1, 1024, 0, st>>>(d_frame_offsets, n_utt, 7, tile_off);
         if (D == 13)
             delta_tiled_kernel<13><<<(int)bound, 256, lds, st>>>(d_in, ld_in, bg, D, N, inv_den, d_out, ld_out,
@@ -367,7 +368,7 @@ int dsp_delta_batch(const float* d_in, int64_t ld_in, const int64_t* d_frame_off
         else
             delta_tiled_kernel<0><<<(int)bound, 256, lds, st>>>(d_in, ld_in, bg, D, N, inv_den, d_out, ld_out,
                                                                 d_out_dd, ld_out_dd, 0, tile_off);
-        HIP_TRY(hipFreeAsync(tile_off, st));
+        if (dsp_workspace_pool().release(w, st) != 0) return fail(DSP_EHIP, "workspace release failed");
     } else {
         delta_kernel<<<grid_for(n_frames_total * D, 256), 256, 0, (hipStream_t)stream>>>(
             d_in, ld_in, bg, D, N, inv_den, d_out, ld_out, d_out_dd, ld_out_dd);

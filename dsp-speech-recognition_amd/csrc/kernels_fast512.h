@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "dsp_common.h"
+#include "workspace.h"
 #include "fft_inreg.h"
 
 #define F512_WAVE_FLOATS 2112  // per-wave LDS: 8 frames x 264 floats (staging / exchange alias it)
@@ -681,13 +682,13 @@ static int fast512_launch_t(F512Params P, const void* d_wave, int dtype, const B
             return fast512_launch_k<NROWS, NI, NC, NSTAGE, DSP_WAVE_I16, false>(P, d_wave, bg, d_out, ld_out, P.total_groups, st);
         return fast512_launch_k<NROWS, NI, NC, NSTAGE, DSP_WAVE_F32, false>(P, d_wave, bg, d_out, ld_out, P.total_groups, st);
     }
-    // ragged: build the group tables in a stream-ordered scratch allocation (no host sync)
+    // ragged: build the group tables in a pooled, event-guarded workspace (no host sync)
     const int64_t bound = bg.total_frames / 8 + bg.n_utt;  // >= sum ceil(T_b / 8)
-    int32_t* ws = nullptr;
     const size_t ws_bytes = ((size_t)bg.n_utt + 1 + (size_t)bound) * sizeof(int32_t);
-    if (hipMallocAsync(reinterpret_cast<void**>(&ws), ws_bytes, st) != hipSuccess) return DSP_EHIP;
-    int32_t* group_off = ws;
-    int32_t* group_utt = ws + bg.n_utt + 1;
+    DspWorkspace* w = dsp_workspace_pool().acquire(ws_bytes);
+    if (!w) return DSP_EHIP;
+    int32_t* group_off = static_cast<int32_t*>(w->ptr);
+    int32_t* group_utt = group_off + bg.n_utt + 1;
     f512_group_prefix_kernel<<<1, 1024, 0, st>>>(bg.frame_off, bg.n_utt, group_off);
     const int fill_blocks = (int)((bg.n_utt + 255) / 256 < 1024 ? (bg.n_utt + 255) / 256 : 1024);
     f512_group_fill_kernel<<<fill_blocks, 256, 0, st>>>(group_off, bg.n_utt, group_utt);
@@ -698,7 +699,7 @@ static int fast512_launch_t(F512Params P, const void* d_wave, int dtype, const B
         rc = fast512_launch_k<NROWS, NI, NC, NSTAGE, DSP_WAVE_I16, true>(P, d_wave, bg, d_out, ld_out, bound, st);
     else
         rc = fast512_launch_k<NROWS, NI, NC, NSTAGE, DSP_WAVE_F32, true>(P, d_wave, bg, d_out, ld_out, bound, st);
-    if (hipFreeAsync(ws, st) != hipSuccess && rc == DSP_OK) rc = DSP_EHIP;
+    if (dsp_workspace_pool().release(w, st) != 0 && rc == DSP_OK) rc = DSP_EHIP;
     return rc;
 }
 

@@ -1,0 +1,77 @@
+// Small device workspaces for the ragged-batch index tables (group / tile prefixes).
+//
+// The tables are produced and consumed by kernels of ONE call on ONE stream, so the host never
+// needs to wait for them -- but the buffer must not be handed to another call while those kernels
+// may still be running.  Each buffer therefore carries an event recorded behind its last user; a
+// buffer is reused only once that event has completed, otherwise a new one is allocated (this only
+// happens while warming up: steady state is lock + hipEventQuery, no allocation, no host sync).
+//
+// hipMallocAsync/hipFreeAsync were used here first; on the legacy default stream they let a later
+// call's tables overwrite an earlier call's while its kernel was still reading them (flaky ragged
+// parity on gfx950 / ROCm 7.2), hence the explicit event guard.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <vector>
+
+struct DspWorkspace {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    hipEvent_t done = nullptr;
+    int device = -1;
+    bool leased = false;
+};
+
+class DspWorkspacePool {
+  public:
+    // Returns nullptr on HIP failure.  The buffer stays leased until release().
+    DspWorkspace* acquire(size_t bytes) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+        if (bytes < 256) bytes = 256;
+        std::lock_guard<std::mutex> lk(mu_);
+        for (DspWorkspace* w : all_) {
+            if (w->leased || w->device != dev || w->bytes < bytes) continue;
+            if (hipEventQuery(w->done) != hipSuccess) {  // still in flight (or error): skip
+                (void)hipGetLastError();
+                continue;
+            }
+            w->leased = true;
+            return w;
+        }
+        DspWorkspace* w = new DspWorkspace();
+        // round up so that slightly larger batches reuse the buffer
+        size_t cap = 4096;
+        while (cap < bytes) cap *= 2;
+        if (hipMalloc(&w->ptr, cap) != hipSuccess ||
+            hipEventCreateWithFlags(&w->done, hipEventDisableTiming) != hipSuccess) {
+            if (w->ptr) (void)hipFree(w->ptr);
+            delete w;
+            return nullptr;
+        }
+        w->bytes = cap;
+        w->device = dev;
+        w->leased = true;
+        all_.push_back(w);
+        return w;
+    }
+
+    // Marks the buffer reusable once everything queued on `st` so far has finished.
+    int release(DspWorkspace* w, hipStream_t st) {
+        hipError_t e = hipEventRecord(w->done, st);
+        std::lock_guard<std::mutex> lk(mu_);
+        w->leased = false;
+        return e == hipSuccess ? 0 : -1;
+    }
+
+  private:
+    std::mutex mu_;
+    std::vector<DspWorkspace*> all_;  // lives for the process (a handful of small buffers)
+};
+
+inline DspWorkspacePool& dsp_workspace_pool() {
+    static DspWorkspacePool* pool = new DspWorkspacePool();  // never destroyed: no teardown-order issues with HIP
+    return *pool;
+}

@@ -91,6 +91,36 @@ def test_ragged_batch_vs_oracle(plan):
         assert normwise(out[fo[b]:fo[b + 1]], ref) <= TOL, (b, n)
 
 
+def test_ragged_calls_queued_back_to_back(plan):
+    """Ragged calls build their index tables in pooled device workspaces.  Queue many calls with
+    different layouts on the default stream WITHOUT host syncs in between: every result must equal
+    (bitwise) the same call run alone.  Guards the workspace lifetime (a buffer may only be reused
+    once the kernels of its previous call have finished)."""
+    from features import _native as nat
+    rng = np.random.default_rng(151)
+    jobs = []
+    for j in range(12):
+        n_utt = int(rng.integers(3, 40))
+        lens = rng.integers(1, 9000, n_utt)
+        so = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        flat = (0.25 * rng.standard_normal(so[-1])).astype(np.float32)
+        alone, fo = plan.mfcc_batch(flat, sample_offsets=so, delta_n=2)
+        jobs.append((flat, so, alone.copy()))
+    held = []
+    for flat, so, _ in jobs:  # allocations and uploads synchronise: do them all up front
+        lay = plan.layout(flat, so)
+        held.append((lay, nat.DeviceBuffer(flat.nbytes).upload(flat),
+                     nat.DeviceBuffer(lay.total_frames * 39 * 4)))
+    for rep in range(5):
+        for lay, d_wave, d_out in held:
+            nat.check(nat.load().dsp_memset(d_out.ptr, 0, d_out.nbytes, None))
+        for lay, d_wave, d_out in held:
+            plan.run_raw(d_wave.ptr, nat.WAVE_F32, lay, d_out.ptr, delta_n=2)
+        for j, (lay, d_wave, d_out) in enumerate(held):
+            got = d_out.download((lay.total_frames, 39), np.float32)
+            assert np.array_equal(got, jobs[j][2]), (rep, j)
+
+
 def test_parseval_full_size():
     """Oracle-free property: sum_n frame[n]^2 == pspec[0] + 2 sum_{0<k<256} pspec[k] + pspec[256]
      on an 8 s signal through the framesig / powspec kernels."""
