@@ -6,9 +6,9 @@
 // buffer is reused only once that event has completed, otherwise a new one is allocated (this only
 // happens while warming up: steady state is lock + hipEventQuery, no allocation, no host sync).
 //
-// hipMallocAsync/hipFreeAsync were used here first; on the legacy default stream they let a later
-// call's tables overwrite an earlier call's while its kernel was still reading them (flaky ragged
-// parity on gfx950 / ROCm 7.2), hence the explicit event guard.
+// hipMallocAsync/hipFreeAsync were used here first; with them, ragged calls queued back to back on
+// the legacy default stream gave intermittently wrong results on gfx950 / ROCm 7.2 (see
+// tests/test_gpu_batch.py::test_ragged_calls_queued_back_to_back), hence the explicit event guard.
 #pragma once
 
 #include <hip/hip_runtime.h>
