@@ -22,6 +22,7 @@ struct dsp_plan {
     float* d_mel_w;         // [mel_nnz]
     float* d_dct;           // [C, M]
     void* d_fast;           // tables of the specialised NFFT=512 kernel (NULL if not applicable)
+    void* d_fast1536;       // tables of the specialised NFFT=1536 kernel (NULL if not applicable)
     int device;
 };
 

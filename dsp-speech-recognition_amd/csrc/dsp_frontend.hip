@@ -12,6 +12,7 @@
 #include "dsp_common.h"
 #include "kernels_generic.h"
 #include "kernels_fast512.h"
+#include "kernels_fast1536.h"
 
 namespace {
 
@@ -113,7 +114,7 @@ int dsp_debug_force_generic(int on) {
     return DSP_OK;
 }
 
-int dsp_plan_has_fast_path(const dsp_plan* plan) { return plan && plan->d_fast ? 1 : 0; }
+int dsp_plan_has_fast_path(const dsp_plan* plan) { return plan && (plan->d_fast || plan->d_fast1536) ? 1 : 0; }
 
 const char* dsp_last_error(void) { return g_err.c_str(); }
 
@@ -236,6 +237,7 @@ int dsp_plan_create(const dsp_plan_desc* d, dsp_plan** out) {
         if (rc == DSP_OK && d->numcep > 0) rc = upload(&p->d_dct, d->h_dct, (size_t)d->numcep * d->nfilt);
     }
     if (rc == DSP_OK) rc = fast512_plan_init(p, d, off.data());
+    if (rc == DSP_OK && d->nfilt > 0 && d->numcep > 0) rc = fast1536_plan_init(p, d, off.data());
     if (rc != DSP_OK) { dsp_plan_destroy(p); return rc; }
     *out = p;
     return DSP_OK;
@@ -246,6 +248,7 @@ int dsp_plan_destroy(dsp_plan* p) {
     void* bufs[] = {p->d_window, p->d_twiddle, p->d_mel_start, p->d_mel_count, p->d_mel_off, p->d_mel_w, p->d_dct};
     for (void* b : bufs) (void)hipFree(b);
     fast512_plan_free(p);
+    fast1536_plan_free(p);
     delete p;
     return DSP_OK;
 }
@@ -317,6 +320,8 @@ int dsp_features_batch(const dsp_plan* plan, const void* d_wave, int wave_dtype,
     hipStream_t st = (hipStream_t)stream;
     if (out_kind == DSP_OUT_MFCC && !g_force_generic.load() && fast512_applicable(plan, bg, d_wave, wave_dtype))
         return fast512_launch(plan, d_wave, wave_dtype, bg, d_out, ld_out, st);
+    if (out_kind == DSP_OUT_MFCC && !g_force_generic.load() && fast1536_applicable(plan, bg, d_wave, wave_dtype))
+        return fast1536_launch(plan, d_wave, wave_dtype, bg, d_out, ld_out, st);
     return launch_generic(plan, d_wave, wave_dtype, bg, out_kind, d_out, ld_out, d_out2, st);
 }
 

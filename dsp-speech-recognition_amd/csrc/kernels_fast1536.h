@@ -1,0 +1,538 @@
+// Specialised fused MFCC kernel for NFFT = 1536 = 3 * 512: the transform size the reference's own
+// driver uses (model.py:74 -- 30 ms frames at 44.1 / 48 kHz, 26 mel filters).
+//
+// Work decomposition (gfx950, wave64):
+//   * one wavefront = 4 consecutive frames of one utterance, 16 lanes per frame (lane = 16 f + c);
+//   * the 1536-point real DFT is split by one decimation-in-frequency radix-3 step,
+//         X[3q + s] = FFT512(y_s)[q],  y_s[m] = (a + W3^s b + W3^2s c) W1536^(s m),
+//         a, b, c = windowed samples m, m + 512, m + 1024,
+//     and because the input is real only s = 0 (y_0 real, bins 3q, q <= 256) and s = 1 (y_1
+//     complex, bins 3q + 1 for q < 256 and, mirrored, bins 1535 - 3q for q >= 256) are needed;
+//   * each 512-point FFT is split m = 16 n1 + n2 exactly like the NFFT = 512 kernel: lane c owns
+//     column n2 = c -> one in-register complex FFT32 over n1, twiddle W512^(c k1), exchange through
+//     LDS (two rounds of 16 rows, XOR-swizzled 16-byte slots, conflict-free both ways), then lane c
+//     owns rows k1 = c and c + 16 -> two in-register FFT16 over n2 -> Y[k1 + 32 k2];
+//   * all power values stay in registers until both FFTs are done, so the per-wave LDS region is
+//     reused three times (staged samples -> exchange buffer -> one 776-float spectrum row per
+//     frame) and 8 waves fit a CU next to ~30 KB of tables;
+//   * |X|^2 / 1536 -> LDS row -> table-driven sparse mel (lane c owns filters c, c + 16, ...) ->
+//     log -> DCT*lifter partial sums -> 4-step DPP all-reduce over the frame's 16 lanes -> store.
+// Samples are read from HBM once per wave (3 S + 1536 of them, 16 B per lane), pre-emphasised on
+// the fly and staged in LDS exactly as in kernels_fast512.h (whose staging helpers are reused).
+#pragma once
+
+#include "kernels_fast512.h"
+
+#define F1536_PS_STRIDE 776    // 769 bins + padding; == 8 (mod 64)
+#define F1536_XSTRIDE 544      // exchange buffer per frame: 16 rows x 32 floats + 32 (bank offset)
+#define F1536_MAX_NI 4
+#define F1536_WAVES 8
+
+struct F1536Params {
+    const float* tables;   // device blob copied to LDS by every workgroup
+    int32_t tab_floats;
+    int32_t off_w3, off_tw, off_dct, off_melw, off_mels;
+    int32_t melw_row;
+    int32_t L, S, M, C, append_energy;
+    float preemph;
+    int32_t span_vec;      // ceil((3 S + 1536) / 4): 16-byte vectors staged per wave
+    int32_t wave_floats;   // per-wave LDS region
+    int32_t len[F1536_MAX_NI];
+    int64_t groups_per_utt, total_groups;
+    const int32_t* group_off;   // ragged: [B+1] prefix of ceil(T_b / 4)
+    const int32_t* group_utt;
+};
+
+struct Fast1536Plan {
+    float* d_tables;
+    F1536Params P;
+    int variant;
+};
+
+// Sum over the 16 lanes of a frame (one DPP row); every lane ends with the total.
+__device__ __forceinline__ float frame16_allreduce(float v) {
+    v += dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);  // row_half_mirror
+    v += dpp_f32<0x140>(v);  // row_mirror
+    return v;
+}
+
+template <bool RAGGED>
+__device__ __forceinline__ F512Group f1536_locate(const F1536Params& P, const BatchGeom& bg, int G) {
+    F512Group g;
+    if constexpr (RAGGED) {
+        g.utt = P.group_utt[G];
+        g.t0 = (G - P.group_off[g.utt]) * 4;
+        g.s0 = bg.sample_off[g.utt];
+        g.nsamp = (int)(bg.sample_off[g.utt + 1] - g.s0);
+        g.row0 = bg.frame_off[g.utt];
+        g.T = (int)(bg.frame_off[g.utt + 1] - g.row0);
+    } else {
+        const int gpu = (int)P.groups_per_utt;
+        g.utt = G / gpu;
+        g.t0 = (G - g.utt * gpu) * 4;
+        g.nsamp = (int)bg.uniform_samples;
+        g.T = (int)bg.uniform_frames;
+        g.s0 = (int64_t)g.utt * bg.uniform_samples;
+        g.row0 = (int64_t)g.utt * bg.uniform_frames;
+    }
+    return g;
+}
+
+// Complex 512-point FFT of one frame spread over its 16 lanes.  In: z[n1] = y[16 n1 + c].
+// Out: pa[k2] = |Y[c + 32 k2]|^2 * scale, pb[k2] = |Y[16 + c + 32 k2]|^2 * scale.
+__device__ __forceinline__ void f1536_cfft512(cpx (&z)[32], float* __restrict__ xb, const float2* __restrict__ s_tw,
+                                              int c, float scale, float (&pa)[16], float (&pb)[16]) {
+    FFTReg<32>::template run<32>(z);
+#pragma unroll
+    for (int k1 = 1; k1 < 32; ++k1) {
+        const float2 t = s_tw[(k1 - 1) * 16 + c];
+        z[k1] = cmulc(z[k1], t.x, t.y);
+    }
+    float* wr = xb + 2 * (c & 1);
+    const int ch = c >> 1;
+    // round A: rows 0..15.  Element (row r, column c) sits in 16-byte slot (c >> 1) ^ (r >> 1).
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        *reinterpret_cast<float2*>(wr + r * 32 + 4 * (ch ^ (r >> 1))) = make_float2(z[r].x, z[r].y);
+    F512_FENCE();
+    cpx u[16];
+    const float* rd = xb + c * 32;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float4 t = *reinterpret_cast<const float4*>(rd + 4 * (i ^ ch));
+        u[2 * i] = {t.x, t.y};
+        u[2 * i + 1] = {t.z, t.w};
+    }
+    F512_FENCE();
+    // round B: rows 16..31 (LDS operations of one wave execute in order: the reads above are done)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        *reinterpret_cast<float2*>(wr + r * 32 + 4 * (ch ^ (r >> 1))) = make_float2(z[16 + r].x, z[16 + r].y);
+    F512_FENCE();
+    FFTReg<16>::run(u);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) pa[k] = scale * fmaf(u[k].x, u[k].x, u[k].y * u[k].y);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float4 t = *reinterpret_cast<const float4*>(rd + 4 * (i ^ ch));
+        u[2 * i] = {t.x, t.y};
+        u[2 * i + 1] = {t.z, t.w};
+    }
+    F512_FENCE();
+    FFTReg<16>::run(u);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) pb[k] = scale * fmaf(u[k].x, u[k].x, u[k].y * u[k].y);
+}
+
+template <int NI, int NC, int NSTAGE, int DTYPE, int WAVES, bool RAGGED>
+__global__ __launch_bounds__(64 * WAVES, 2) void mfcc1536_kernel(F1536Params P, BatchGeom bg,
+                                                                 const void* __restrict__ wave,
+                                                                 float* __restrict__ out, int64_t ld_out) {
+    extern __shared__ __attribute__((aligned(256))) float smem_f[];
+    float* const smem = smem_f;
+    const int tid = threadIdx.x;
+    for (int i = tid * 4; i < P.tab_floats; i += 64 * WAVES * 4)
+        *reinterpret_cast<float4*>(smem + i) = *reinterpret_cast<const float4*>(P.tables + i);
+    __syncthreads();
+    const float* s_win = smem;
+    const float2* s_w3 = reinterpret_cast<const float2*>(smem + P.off_w3);
+    const float2* s_tw = reinterpret_cast<const float2*>(smem + P.off_tw);
+    const float* s_dct = smem + P.off_dct;
+    const float* s_melw = smem + P.off_melw;
+
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* wbuf = smem + P.tab_floats + wid * P.wave_floats;
+    const int total_groups = RAGGED ? P.group_off[bg.n_utt] : (int)P.total_groups;
+    const int gstride = (int)gridDim.x * WAVES;
+
+    for (int G = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WAVES + wid); G < total_groups; G += gstride) {
+        int lane = tid & 63;
+        asm volatile("" : "+v"(lane));  // keep lane-derived addresses out of loop-invariant registers
+        const int f = lane >> 4, c = lane & 15;
+        const F512Group grp = f1536_locate<RAGGED>(P, bg, G);
+        const int t0 = grp.t0, T = grp.T, nsamp = grp.nsamp;
+        const int base = t0 * P.S;
+        const int64_t g0 = grp.s0 + base;
+        const int d = RAGGED ? (int)(g0 & 3) : 0;
+
+        // ---- stage 3 S + 1536 (+ d) samples: aligned 16 B loads, pre-emphasis, zero fill ----
+        {
+            const int64_t a0 = g0 - d;
+            const int span_vec = RAGGED ? P.span_vec + 1 : P.span_vec;
+            F512Raw<DTYPE> raw[NSTAGE];
+#pragma unroll
+            for (int r = 0; r < NSTAGE; ++r) {
+                const int v = lane + 64 * r;
+                const int rel = base - d + 4 * v;
+                const bool touch = v < span_vec && rel + 3 >= 0 && rel < nsamp;
+                raw[r] = f512_load_raw<DTYPE>(wave, touch ? a0 + 4 * v : 0);
+            }
+            float left = (base - d > 0) ? dsp_load_sample<DTYPE>(wave, a0 - 1) : 0.f;
+#pragma unroll
+            for (int r = 0; r < NSTAGE; ++r) {
+                const int v = lane + 64 * r;
+                const int rel = base - d + 4 * v;
+                float x[4];
+                f512_unpack<DTYPE>(raw[r], x);
+                const float prev = f512_shift_in(x[3], left);
+                left = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[3]), 63));
+                float4 y;
+                y.x = fmaf(-P.preemph, prev, x[0]);
+                y.y = fmaf(-P.preemph, x[0], x[1]);
+                y.z = fmaf(-P.preemph, x[1], x[2]);
+                y.w = fmaf(-P.preemph, x[2], x[3]);
+                if constexpr (RAGGED) {
+                    if (rel + 0 == 0) y.x = x[0];
+                    if (rel + 1 == 0) y.y = x[1];
+                    if (rel + 2 == 0) y.z = x[2];
+                    if (rel + 3 == 0) y.w = x[3];
+                    if (rel + 0 < 0 || rel + 0 >= nsamp) y.x = 0.f;
+                    if (rel + 1 < 0 || rel + 1 >= nsamp) y.y = 0.f;
+                    if (rel + 2 < 0 || rel + 2 >= nsamp) y.z = 0.f;
+                    if (rel + 3 < 0 || rel + 3 >= nsamp) y.w = 0.f;
+                } else {
+                    const uint32_t m = (v < span_vec && rel < nsamp) ? 0xffffffffu : 0u;
+                    y.x = __uint_as_float(__float_as_uint(y.x) & m);
+                    y.y = __uint_as_float(__float_as_uint(y.y) & m);
+                    y.z = __uint_as_float(__float_as_uint(y.z) & m);
+                    y.w = __uint_as_float(__float_as_uint(y.w) & m);
+                }
+                if (v < span_vec) *reinterpret_cast<float4*>(wbuf + 4 * v) = y;
+            }
+        }
+        F512_FENCE();
+
+        // ---- radix-3 step: y_0 (real) and y_1 (complex) of column c, rows n1 = 0..31 ----
+        float y0[32];
+        cpx y1[32];
+        {
+            const float* xp = wbuf + d + f * P.S + c;
+            const float* wp = s_win + c;
+            const float2* w3p = s_w3 + c;
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1) {
+                const float a = xp[16 * n1] * wp[16 * n1];
+                const float b = xp[512 + 16 * n1] * wp[512 + 16 * n1];
+                const float e = xp[1024 + 16 * n1] * wp[1024 + 16 * n1];
+                const float sbe = b + e;
+                y0[n1] = a + sbe;
+                const float tr = fmaf(-0.5f, sbe, a);                     // Re(a + W3 b + W3^2 e)
+                const float ti = 0.86602540378443864676f * (e - b);        // Im(...)
+                const float2 w = w3p[16 * n1];                             // W1536^(16 n1 + c)
+                y1[n1] = {fmaf(tr, w.x, -ti * w.y), fmaf(tr, w.y, ti * w.x)};
+            }
+        }
+        F512_FENCE();
+
+        constexpr float SC = 1.0f / 1536.0f;
+        float* xb = wbuf + f * F1536_XSTRIDE;
+        float p1a[16], p1b[16], p0a[16], p0b[16];
+        f1536_cfft512(y1, xb, s_tw, c, SC, p1a, p1b);
+        F512_FENCE();
+        {
+            cpx z[32];
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1) z[n1] = {y0[n1], 0.f};
+            f1536_cfft512(z, xb, s_tw, c, SC, p0a, p0b);
+        }
+        F512_FENCE();
+
+        // ---- power spectrum -> LDS row of this frame (every bin written exactly once) ----
+        float* ps = wbuf + f * F1536_PS_STRIDE;
+        float energy = 0.f;
+        {
+            float* q = ps + 3 * c;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                q[96 * k] = p0a[k];                    // bin 3 (c + 32 k)
+                q[48 + 96 * k] = p0b[k];               // bin 3 (16 + c + 32 k)
+                q[1 + 96 * k] = p1a[k];                // bin 3 (c + 32 k) + 1
+                q[49 + 96 * k] = p1b[k];               // bin 3 (16 + c + 32 k) + 1
+                energy += (p0a[k] + p0b[k]) + (p1a[k] + p1b[k]);
+            }
+            float* m = ps - 3 * c;
+#pragma unroll
+            for (int k = 8; k < 16; ++k) {
+                m[1535 - 96 * k] = p1a[k];             // bin 1536 - (3 (c + 32 k) + 1)
+                m[1487 - 96 * k] = p1b[k];             // bin 1536 - (3 (16 + c + 32 k) + 1)
+                energy += p1a[k] + p1b[k];
+            }
+            if (c == 0) {
+                ps[768] = p0a[8];
+                energy += p0a[8];
+            } else if (c < 8) {
+                ps[768 + c] = 0.f;                     // row padding read by zero-weight mel taps
+            }
+        }
+        energy = frame16_allreduce(energy);
+        if (energy == 0.f) energy = DSP_EPS_F32;
+        F512_FENCE();
+
+        // ---- sparse mel triangles, log: lane c owns filters c + 16 i ----
+        float lm[NI];
+        {
+            const float4* wrow = reinterpret_cast<const float4*>(s_melw + c * P.melw_row);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const float4* pb = reinterpret_cast<const float4*>(ps + __float_as_int(smem[P.off_mels + i * 16 + c]));
+                float acc0 = 0.f, acc1 = 0.f;
+                const int nb = P.len[i] >> 3;
+                for (int b = 0; b < nb; ++b) {
+                    const float4 w0 = wrow[2 * b], w1 = wrow[2 * b + 1];
+                    const float4 q0 = pb[2 * b], q1 = pb[2 * b + 1];
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc0 = fmaf(w0.x, q0.x, acc0);
+                    acc1 = fmaf(w0.y, q0.y, acc1);
+                    acc0 = fmaf(w0.z, q0.z, acc0);
+                    acc1 = fmaf(w0.w, q0.w, acc1);
+                    acc0 = fmaf(w1.x, q1.x, acc0);
+                    acc1 = fmaf(w1.y, q1.y, acc1);
+                    acc0 = fmaf(w1.z, q1.z, acc0);
+                    acc1 = fmaf(w1.w, q1.w, acc1);
+                }
+                wrow += 2 * nb;
+                float acc = acc0 + acc1;
+                if (acc == 0.f) acc = DSP_EPS_F32;
+                lm[i] = __logf(acc);
+            }
+        }
+        F512_FENCE();
+
+        // ---- DCT-II * lifter partial sums, all-reduce over the frame's 16 lanes ----
+        float cep[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) cep[k] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const float4* dr = reinterpret_cast<const float4*>(s_dct + (i * 16 + c) * 20);
+#pragma unroll
+            for (int q = 0; q < (NC + 3) / 4; ++q) {
+                const float4 dv = dr[q];
+                if (4 * q + 0 < NC) cep[4 * q + 0] = fmaf(dv.x, lm[i], cep[4 * q + 0]);
+                if (4 * q + 1 < NC) cep[4 * q + 1] = fmaf(dv.y, lm[i], cep[4 * q + 1]);
+                if (4 * q + 2 < NC) cep[4 * q + 2] = fmaf(dv.z, lm[i], cep[4 * q + 2]);
+                if (4 * q + 3 < NC) cep[4 * q + 3] = fmaf(dv.w, lm[i], cep[4 * q + 3]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NC; ++k) cep[k] = frame16_allreduce(cep[k]);
+        if (P.append_energy) cep[0] = __logf(energy);
+
+        float v0 = cep[0];
+#pragma unroll
+        for (int k = 1; k < NC; ++k)
+            if (c == k) v0 = cep[k];
+        const int t = t0 + f;
+        if (t < T && c < P.C) out[(grp.row0 + t) * ld_out + c] = v0;
+        F512_FENCE();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static inline bool fast1536_shape_ok(const dsp_plan_desc* d) {
+    return d->nfft == 1536 && d->frame_len <= 1536 && d->frame_step >= 1 &&
+           (3 * d->frame_step + 1536 + 3) / 4 + 1 <= 16 * 64 && d->nfilt >= 1 &&
+           d->nfilt <= 16 * F1536_MAX_NI && d->numcep >= 1 && d->numcep <= 16;
+}
+
+static inline int fast1536_plan_init(dsp_plan* p, const dsp_plan_desc* d, const int32_t* mel_off) {
+    p->d_fast1536 = nullptr;
+    if (!fast1536_shape_ok(d)) return DSP_OK;
+    const int M = d->nfilt, C = d->numcep, L = d->frame_len;
+    const int ni_real = (M + 15) / 16;
+    const int span_vec = (3 * d->frame_step + 1536 + 3) / 4;
+    const int nstage = (span_vec + 1 + 63) / 64;
+    int variant, NI;
+    if (ni_real <= 2 && C <= 13 && nstage <= 12) { variant = 0; NI = 2; }
+    else { variant = 1; NI = F1536_MAX_NI; }
+    Fast1536Plan* fp = new Fast1536Plan();
+    memset(fp, 0, sizeof(*fp));
+
+    std::vector<float> win(1536, 0.f);
+    for (int n = 0; n < L; ++n) win[n] = d->h_window[n];
+    std::vector<float> w3(2 * 512), tw(2 * 31 * 16);
+    for (int m = 0; m < 512; ++m) {
+        const double a = -2.0 * M_PI * (double)m / 1536.0;
+        w3[2 * m] = (float)cos(a);
+        w3[2 * m + 1] = (float)sin(a);
+    }
+    for (int k1 = 1; k1 < 32; ++k1)
+        for (int c = 0; c < 16; ++c) {
+            const double a = -2.0 * M_PI * (double)(c * k1) / 512.0;
+            tw[2 * ((k1 - 1) * 16 + c)] = (float)cos(a);
+            tw[2 * ((k1 - 1) * 16 + c) + 1] = (float)sin(a);
+        }
+    std::vector<float> dct((size_t)NI * 16 * 20, 0.f);
+    for (int i = 0; i < NI; ++i)
+        for (int c = 0; c < 16; ++c) {
+            const int j = c + 16 * i;
+            if (j >= M) continue;
+            for (int k = 0; k < C; ++k) dct[((size_t)i * 16 + c) * 20 + k] = d->h_dct[(size_t)k * M + j];
+        }
+    // mel: one weight row per lane (filter groups back to back), every filter read from a bin that is
+    // a multiple of 4, every group padded to a multiple of 8 taps; padded reads stay inside the row.
+    // A filter whose padded read would cross the end of the row is read from an earlier start
+    // (more leading zero weights), which may lengthen the group: iterate to the fixed point.
+    auto placed_start = [](int mel_start, int len) {
+        int start = mel_start & ~3;
+        if (start + len > F1536_PS_STRIDE) start = (F1536_PS_STRIDE - len) & ~3;
+        return start;
+    };
+    bool ok = true;
+    int row_floats = 0;
+    for (int i = 0; i < NI; ++i) {
+        int len = 8;
+        for (int it = 0; it < 8; ++it) {
+            int need = 0;
+            for (int c = 0; c < 16; ++c) {
+                const int j = c + 16 * i;
+                if (j >= M) continue;
+                const int n = d->h_mel_start[j] - placed_start(d->h_mel_start[j], len) + d->h_mel_count[j];
+                if (n > need) need = n;
+            }
+            need = (need + 7) / 8 * 8;
+            if (need <= len) break;
+            len = need;
+        }
+        if (len > F1536_PS_STRIDE) ok = false;
+        fp->P.len[i] = len;
+        row_floats += len;
+    }
+    int melw_row = row_floats > 0 ? row_floats : 8;
+    if (((melw_row / 4) & 1) == 0) melw_row += 4;
+    std::vector<float> melw((size_t)16 * melw_row, 0.f), mels((size_t)NI * 16, 0.f);
+    for (int c = 0; c < 16 && ok; ++c) {
+        int pos = 0;
+        for (int i = 0; i < NI; ++i) {
+            const int j = c + 16 * i, len = fp->P.len[i];
+            int32_t start = 0;
+            if (j < M) {
+                start = placed_start(d->h_mel_start[j], len);
+                const int lead = d->h_mel_start[j] - start;
+                if (start < 0 || lead + d->h_mel_count[j] > len) { ok = false; break; }
+                for (int s2 = 0; s2 < d->h_mel_count[j]; ++s2)
+                    melw[(size_t)c * melw_row + pos + lead + s2] = d->h_mel_weights[mel_off[j] + s2];
+            }
+            memcpy(&mels[(size_t)i * 16 + c], &start, 4);
+            pos += len;
+        }
+    }
+    auto pad64 = [](size_t n) { return (n + 63) / 64 * 64; };
+    const size_t o_w3 = 1536, o_tw = o_w3 + w3.size(), o_dct = o_tw + tw.size();
+    const size_t o_melw = pad64(o_dct + dct.size()), o_mels = o_melw + melw.size();
+    const size_t total = pad64(o_mels + mels.size());
+    size_t wave_floats = 4 * F1536_PS_STRIDE;
+    if ((size_t)4 * (span_vec + 1) > wave_floats) wave_floats = (size_t)4 * (span_vec + 1);
+    if ((size_t)4 * F1536_XSTRIDE > wave_floats) wave_floats = 4 * F1536_XSTRIDE;
+    wave_floats = pad64(wave_floats);
+    if (!ok || (total + F1536_WAVES * wave_floats) * 4 > 160 * 1024) {  // does not fit one CU's LDS: generic kernel
+        delete fp;
+        return DSP_OK;
+    }
+    std::vector<float> blob(total, 0.f);
+    memcpy(blob.data(), win.data(), 1536 * 4);
+    memcpy(blob.data() + o_w3, w3.data(), w3.size() * 4);
+    memcpy(blob.data() + o_tw, tw.data(), tw.size() * 4);
+    memcpy(blob.data() + o_dct, dct.data(), dct.size() * 4);
+    memcpy(blob.data() + o_melw, melw.data(), melw.size() * 4);
+    memcpy(blob.data() + o_mels, mels.data(), mels.size() * 4);
+    if (hipMalloc(reinterpret_cast<void**>(&fp->d_tables), total * 4) != hipSuccess ||
+        hipMemcpy(fp->d_tables, blob.data(), total * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        if (fp->d_tables) (void)hipFree(fp->d_tables);
+        delete fp;
+        return DSP_EHIP;
+    }
+    fp->P.tables = fp->d_tables;
+    fp->P.tab_floats = (int32_t)total;
+    fp->P.off_w3 = (int32_t)o_w3; fp->P.off_tw = (int32_t)o_tw; fp->P.off_dct = (int32_t)o_dct;
+    fp->P.off_melw = (int32_t)o_melw; fp->P.off_mels = (int32_t)o_mels; fp->P.melw_row = melw_row;
+    fp->P.L = L; fp->P.S = d->frame_step; fp->P.M = M; fp->P.C = C;
+    fp->P.append_energy = d->append_energy ? 1 : 0;
+    fp->P.preemph = d->preemph;
+    fp->P.span_vec = span_vec;
+    fp->P.wave_floats = (int32_t)wave_floats;
+    fp->variant = variant;
+    p->d_fast1536 = fp;
+    return DSP_OK;
+}
+
+static inline void fast1536_plan_free(dsp_plan* p) {
+    Fast1536Plan* fp = static_cast<Fast1536Plan*>(p->d_fast1536);
+    if (!fp) return;
+    (void)hipFree(fp->d_tables);
+    delete fp;
+    p->d_fast1536 = nullptr;
+}
+
+static inline bool fast1536_applicable(const dsp_plan* p, const BatchGeom& bg, const void* d_wave, int dtype) {
+    if (!p->d_fast1536) return false;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(d_wave);
+    if ((a % (dtype == DSP_WAVE_I16 ? 8 : 16)) != 0) return false;
+    if (bg.uniform_samples > 0) {
+        if ((bg.uniform_samples % 4) != 0) return false;
+        return bg.uniform_samples <= 0x3fffffff && ((bg.uniform_frames + 3) / 4) * bg.n_utt <= 0x3fffffff;
+    }
+    return bg.total_frames / 4 + bg.n_utt <= 0x3fffffff;
+}
+
+template <int NI, int NC, int NSTAGE, int DTYPE, bool RAGGED>
+static int fast1536_launch_k(const F1536Params& P, const void* d_wave, const BatchGeom& bg, float* d_out,
+                             int64_t ld_out, int64_t groups_bound, hipStream_t st) {
+    const size_t lds = ((size_t)P.tab_floats + (size_t)F1536_WAVES * P.wave_floats) * sizeof(float);
+    const int64_t cap = 256;  // one 8-wave workgroup per CU (LDS bound)
+    int64_t blocks = (groups_bound + F1536_WAVES - 1) / F1536_WAVES;
+    if (blocks > cap) {
+        const int64_t rounds = (blocks + cap - 1) / cap;
+        blocks = (blocks + rounds - 1) / rounds;
+    }
+    auto k = mfcc1536_kernel<NI, NC, NSTAGE, DTYPE, F1536_WAVES, RAGGED>;
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return DSP_EHIP;
+        lds_set = lds;
+    }
+    k<<<(int)blocks, 64 * F1536_WAVES, lds, st>>>(P, bg, d_wave, d_out, ld_out);
+    return hipGetLastError() == hipSuccess ? DSP_OK : DSP_EHIP;
+}
+
+template <int NI, int NC, int NSTAGE>
+static int fast1536_launch_t(F1536Params P, const void* d_wave, int dtype, const BatchGeom& bg, float* d_out,
+                             int64_t ld_out, hipStream_t st) {
+    if (bg.uniform_samples > 0) {
+        P.groups_per_utt = (bg.uniform_frames + 3) / 4;
+        P.total_groups = P.groups_per_utt * bg.n_utt;
+        if (dtype == DSP_WAVE_I16)
+            return fast1536_launch_k<NI, NC, NSTAGE, DSP_WAVE_I16, false>(P, d_wave, bg, d_out, ld_out, P.total_groups, st);
+        return fast1536_launch_k<NI, NC, NSTAGE, DSP_WAVE_F32, false>(P, d_wave, bg, d_out, ld_out, P.total_groups, st);
+    }
+    const int64_t bound = bg.total_frames / 4 + bg.n_utt;  // >= sum ceil(T_b / 4)
+    const size_t ws_bytes = ((size_t)bg.n_utt + 1 + (size_t)bound) * sizeof(int32_t);
+    DspWorkspace* w = dsp_workspace_pool().acquire(ws_bytes);
+    if (!w) return DSP_EHIP;
+    int32_t* group_off = static_cast<int32_t*>(w->ptr);
+    int32_t* group_utt = group_off + bg.n_utt + 1;
+    f512_group_prefix_kernel<<<1, 1024, 0, st>>>(bg.frame_off, bg.n_utt, 2, group_off);
+    const int fill_blocks = (int)((bg.n_utt + 255) / 256 < 1024 ? (bg.n_utt + 255) / 256 : 1024);
+    f512_group_fill_kernel<<<fill_blocks, 256, 0, st>>>(group_off, bg.n_utt, group_utt);
+    P.group_off = group_off;
+    P.group_utt = group_utt;
+    int rc;
+    if (dtype == DSP_WAVE_I16)
+        rc = fast1536_launch_k<NI, NC, NSTAGE, DSP_WAVE_I16, true>(P, d_wave, bg, d_out, ld_out, bound, st);
+    else
+        rc = fast1536_launch_k<NI, NC, NSTAGE, DSP_WAVE_F32, true>(P, d_wave, bg, d_out, ld_out, bound, st);
+    if (dsp_workspace_pool().release(w, st) != 0 && rc == DSP_OK) rc = DSP_EHIP;
+    return rc;
+}
+
+static inline int fast1536_launch(const dsp_plan* p, const void* d_wave, int dtype, const BatchGeom& bg,
+                                  float* d_out, int64_t ld_out, hipStream_t st) {
+    const Fast1536Plan* fp = static_cast<const Fast1536Plan*>(p->d_fast1536);
+    if (fp->variant == 0) return fast1536_launch_t<2, 13, 12>(fp->P, d_wave, dtype, bg, d_out, ld_out, st);
+    return fast1536_launch_t<4, 16, 16>(fp->P, d_wave, dtype, bg, d_out, ld_out, st);
+}

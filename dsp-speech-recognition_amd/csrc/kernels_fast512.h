@@ -486,16 +486,17 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
     }
 }
 
-// Ragged batches: group_off[b] = sum_{i<b} ceil(T_i / 8) (exclusive prefix, single block), then the
+// Ragged batches: group_off[b] = sum_{i<b} ceil(T_i / 2^shift) (exclusive prefix, single block), then the
 // utterance of every group.  Both are tiny next to the main kernel and run on the same stream.
 __global__ __launch_bounds__(1024) void f512_group_prefix_kernel(const int64_t* __restrict__ frame_off, int32_t n_utt,
-                                                                 int32_t* __restrict__ group_off) {
+                                                                 int32_t shift, int32_t* __restrict__ group_off) {
     __shared__ int32_t part[1024];
     const int tid = threadIdx.x;
     const int per = (n_utt + 1023) / 1024;
     const int lo = tid * per, hi = min(lo + per, n_utt);
+    const int64_t rnd = ((int64_t)1 << shift) - 1;
     int32_t sum = 0;
-    for (int b = lo; b < hi; ++b) sum += (int32_t)((frame_off[b + 1] - frame_off[b] + 7) >> 3);
+    for (int b = lo; b < hi; ++b) sum += (int32_t)((frame_off[b + 1] - frame_off[b] + rnd) >> shift);
     part[tid] = sum;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan of the per-thread sums
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(1024) void f512_group_prefix_kernel(const int64_t* 
     int32_t run = part[tid] - sum;
     for (int b = lo; b < hi; ++b) {
         group_off[b] = run;
-        run += (int32_t)((frame_off[b + 1] - frame_off[b] + 7) >> 3);
+        run += (int32_t)((frame_off[b + 1] - frame_off[b] + rnd) >> shift);
     }
     if (tid == 1023) group_off[n_utt] = part[1023];
 }
@@ -689,7 +690,7 @@ static int fast512_launch_t(F512Params P, const void* d_wave, int dtype, const B
     if (!w) return DSP_EHIP;
     int32_t* group_off = static_cast<int32_t*>(w->ptr);
     int32_t* group_utt = group_off + bg.n_utt + 1;
-    f512_group_prefix_kernel<<<1, 1024, 0, st>>>(bg.frame_off, bg.n_utt, group_off);
+    f512_group_prefix_kernel<<<1, 1024, 0, st>>>(bg.frame_off, bg.n_utt, 3, group_off);
     const int fill_blocks = (int)((bg.n_utt + 255) / 256 < 1024 ? (bg.n_utt + 255) / 256 : 1024);
     f512_group_fill_kernel<<<fill_blocks, 256, 0, st>>>(group_off, bg.n_utt, group_utt);
     P.group_off = group_off;

@@ -234,6 +234,46 @@ def test_fast_kernel_instantiations(cfg, dtype):
         assert normwise(out_r[fo_r[b]:fo_r[b + 1]], ref) <= tol, ('ragged', b, lens[b])
 
 
+@pytest.mark.parametrize('cfg', [
+    dict(samplerate=48000, winlen=0.03, winstep=0.01, nfilt=26, numcep=13),                 # model.py:74 at 48 kHz
+    dict(samplerate=44100, winlen=0.03, winstep=0.01, nfilt=26, numcep=13, preemph=0.0),    # L=1323, S=441 (odd)
+    dict(samplerate=48000, winlen=0.032, winstep=0.012, nfilt=40, numcep=16),               # L=1536, 3 mel groups: catch-all
+    dict(samplerate=16000, winlen=0.03, winstep=0.01, nfilt=26, numcep=13),                 # L=480 zero-padded to 1536
+], ids=['48k', '44k1_nopre', 'L1536_M40_C16', '16k_L480'])
+@pytest.mark.parametrize('dtype', [np.float32, np.int16])
+def test_fast1536_kernel(cfg, dtype):
+    """The specialised NFFT=1536 kernel (radix-3 split into a real and a complex 512-point FFT),
+    dense and ragged, fp32 and int16, against the oracle and against the generic kernel."""
+    from features.batch import FeaturePlan
+    from features import _native as nat
+    full = dict(nfft=1536, lowfreq=0, highfreq=None, preemph=0.97, ceplifter=22, appendEnergy=True)
+    full.update(cfg)
+    plan = FeaturePlan(winfunc=np.hamming, **full)
+    lib = nat.load()
+    assert lib.dsp_plan_has_fast_path(plan.plan.handle) == 1
+    rate = full['samplerate']
+    dense = _batch(61, 10, rate // 2, dtype=dtype)
+    out, fo = plan.mfcc_batch(dense, delta_n=3)
+    lens = [rate // 2, 1537, 4097, 1, rate // 3 + 1, 20001, 1440]
+    so = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+    flat = _batch(62, 1, int(so[-1]), dtype=dtype)[0]
+    out_r, fo_r = plan.mfcc_batch(flat, sample_offsets=so, delta_n=3)
+    try:
+        nat.check(lib.dsp_debug_force_generic(1))
+        gen, _ = plan.mfcc_batch(dense, delta_n=3)
+        gen_r, _ = plan.mfcc_batch(flat, sample_offsets=so, delta_n=3)
+    finally:
+        nat.check(lib.dsp_debug_force_generic(0))
+    assert normwise(out, gen) <= 5e-5 and normwise(out_r, gen_r) <= 5e-5
+    for b in range(10):
+        ref = dsp_oracle.mfcc_delta(dense[b].astype(np.float64), delta_n=3, winfunc=np.hamming, **full)
+        assert normwise(out[fo[b]:fo[b + 1]], ref) <= TOL, ('dense', b)
+    for b in range(len(lens)):
+        ref = dsp_oracle.mfcc_delta(flat[so[b]:so[b + 1]].astype(np.float64), delta_n=3, winfunc=np.hamming, **full)
+        assert out_r[fo_r[b]:fo_r[b + 1]].shape == ref.shape
+        assert normwise(out_r[fo_r[b]:fo_r[b + 1]], ref) <= TOL, ('ragged', b, lens[b])
+
+
 def test_odd_hop_uses_generic_kernel_and_matches():
     from features.batch import FeaturePlan
     from features import _native as nat
