@@ -13,6 +13,7 @@
 #include "kernels_generic.h"
 #include "kernels_fast512.h"
 #include "kernels_fast1536.h"
+#include "kernels_vad.h"
 
 namespace {
 
@@ -413,8 +414,14 @@ int dsp_vad_features_batch(const void* d_wave, int wave_dtype, const int64_t* d_
     int rc = check_geom(d_wave, wave_dtype, d_sample_offsets, d_frame_offsets, n_utt, n_frames_total, uniform_samples);
     if (rc != DSP_OK) return rc;
     BatchGeom bg = make_geom(d_sample_offsets, d_frame_offsets, n_utt, n_frames_total, uniform_samples, frame_len, frame_step);
-    const int grid = grid_for(n_frames_total, 4);
     hipStream_t st = (hipStream_t)stream;
+    const int tile = vad_tile_frames(frame_len, frame_step);
+    if (!g_force_generic.load() && vad_tile_applicable(bg, d_wave, wave_dtype, tile)) {
+        rc = vad_tile_launch(tile, frame_len, frame_step, use_sq, bg, d_wave, wave_dtype, d_amp_sum, d_zcr, st);
+        if (rc != DSP_OK) return fail(rc, "vad tile kernel launch failed");
+        return DSP_OK;
+    }
+    const int grid = grid_for(n_frames_total, 4);
     if (wave_dtype == DSP_WAVE_I16)
         vad_features_kernel<DSP_WAVE_I16><<<grid, 256, 0, st>>>(d_wave, bg, frame_len, frame_step, use_sq, d_amp_sum, d_zcr);
     else
@@ -447,7 +454,7 @@ int dsp_endpoint_rule_batch(const double* d_amp_sum, const int32_t* d_zcr, const
     if (!(cfg_frame > 0.0) || !(cfg_step > 0.0)) return fail(DSP_EINVAL, "cfg.frame / cfg.step must be > 0");
     if (2 * (int)(0.100 / cfg_step) > DSP_MAX_SIL)
         return fail(DSP_EINVAL, "cfg.step %g gives a silence window > %d frames", cfg_step, DSP_MAX_SIL);
-    endpoint_rule_kernel<<<(n_utt + 63) / 64, 64, 0, (hipStream_t)stream>>>(
+    endpoint_rule_kernel<<<n_utt, 64, 0, (hipStream_t)stream>>>(
         d_amp_sum, d_zcr, d_frame_offsets, n_utt, frame_len, cfg_frame, cfg_step, d_endpoints);
     HIP_TRY(hipGetLastError());
     return DSP_OK;

@@ -26,7 +26,9 @@
 #define F1536_PS_STRIDE 776    // 769 bins + padding; == 8 (mod 64)
 #define F1536_XSTRIDE 544      // exchange buffer per frame: 16 rows x 32 floats + 32 (bank offset)
 #define F1536_MAX_NI 4
+#ifndef F1536_WAVES
 #define F1536_WAVES 8
+#endif
 
 struct F1536Params {
     const float* tables;   // device blob copied to LDS by every workgroup

@@ -382,10 +382,9 @@ __global__ __launch_bounds__(256) void vad_features_kernel(const void* __restric
 
 // endpoint.amplitude_rule (endpoint.py:133-179, use_acr=False): only the first segment's start and
 // the last segment's end are consumed by basic_endpoint_detection (endpoint.py:43,49).
-__device__ inline void amplitude_rule_dev(const double* __restrict__ amp, int64_t T, double inv_L, double mh,
+__device__ inline void amplitude_rule_dev(const double* amp, int64_t T, double inv_L, double mh,
                                           double th, int n_l, int n_r, double sigma, double cfg_frame,
-                                          int64_t& left, int64_t& right) {
-    double sil[DSP_MAX_SIL];
+                                          double* sil, int64_t& left, int64_t& right) {
     int ns = 0;
     const int64_t cl = n_l < T ? n_l : T;                   // amp[:n_l]
     for (int64_t i = 0; i < cl; ++i) sil[ns++] = amp[i] * inv_L;
@@ -430,23 +429,42 @@ __device__ inline void amplitude_rule_dev(const double* __restrict__ amp, int64_
     if (!any) { left = 0; right = T; }
 }
 
+#define DSP_RULE_LDS_FRAMES 2048   // utterances up to this many frames are scanned out of LDS
+
+// One wavefront per utterance: the wave copies the utterance's amp / zcr rows into LDS (coalesced),
+// then lane 0 runs the sequential state machines against LDS instead of HBM (the scan is a chain of
+// dependent loads: ~1 us each from HBM, ~0.05 us from LDS).
 __global__ __launch_bounds__(64) void endpoint_rule_kernel(const double* __restrict__ amp_sum,
                                                            const int32_t* __restrict__ zcr,
                                                            const int64_t* __restrict__ frame_off, int32_t n_utt,
                                                            int32_t L, double cfg_frame, double cfg_step,
                                                            int32_t* __restrict__ endpoints) {
-    const int32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double s_amp[DSP_RULE_LDS_FRAMES];
+    __shared__ int32_t s_zcr[DSP_RULE_LDS_FRAMES];
+    __shared__ double s_sil[DSP_MAX_SIL];
+    const int32_t b = blockIdx.x;
     if (b >= n_utt) return;
     const int64_t base = frame_off[b];
     const int64_t T = frame_off[b + 1] - base;
     const double* amp = amp_sum + base;
     const int32_t* z = zcr + base;
+    if (T <= DSP_RULE_LDS_FRAMES) {
+        for (int i = threadIdx.x; i < (int)T; i += 64) {
+            s_amp[i] = amp[i];
+            s_zcr[i] = z[i];
+        }
+        __syncthreads();
+        amp = s_amp;
+        z = s_zcr;
+    }
+    if (threadIdx.x != 0) return;
+    double* sil = s_sil;
     const double inv_L = 1.0 / (double)L;
     const int n_sil = (int)(0.100 / cfg_step);              // int(l_sil / cfg.step), endpoint.py:151
     int64_t left = 0, right = T;
-    amplitude_rule_dev(amp, T, inv_L, 0.25, 0.100, n_sil, n_sil, 3.0, cfg_frame, left, right);
+    amplitude_rule_dev(amp, T, inv_L, 0.25, 0.100, n_sil, n_sil, 3.0, cfg_frame, sil, left, right);
     if (right - left < 50)                                  // endpoint.py:44-45
-        amplitude_rule_dev(amp, T, inv_L, 0.125, 0.100, n_sil, n_sil, 3.0, cfg_frame, left, right);
+        amplitude_rule_dev(amp, T, inv_L, 0.125, 0.100, n_sil, n_sil, 3.0, cfg_frame, sil, left, right);
     // zcr_rule, endpoint.py:201-220 (l_sil = 0 -> front slice empty; r_sil = 0.1)
     const double max_shift = 0.400 / cfg_frame;
     const int64_t cr = (n_sil == 0 || n_sil > T) ? T : n_sil;

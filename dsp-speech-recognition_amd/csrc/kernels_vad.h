@@ -1,0 +1,225 @@
+// Tiled short-time amplitude / zero-crossing kernel for the endpointing path
+// (endpoint.get_amplitude, endpoint.py:109-126; endpoint.get_zcr, endpoint.py:182-198; frames from
+// sigproc.to_frames, sigproc.py:11-19).
+//
+// One wavefront = FR consecutive frames of one utterance, 64 / FR lanes per frame.  The
+// (FR - 1) S + L samples the frames cover are read from HBM once (aligned 16 B per lane, the staging
+// scheme of kernels_fast512.h without the pre-emphasis), converted to fp32 (exact for int16) and
+// parked in LDS; every lane then walks its frame with plain b32 reads.  Sums are order independent,
+// so frame f starts its walk rot_f elements into the frame, rot_f chosen such that the FR frames
+// of a wave instruction hit disjoint LDS banks whatever the hop is.  fp64 accumulation.
+#pragma once
+
+#include "kernels_fast512.h"
+
+#define VAD_NSTAGE 12   // 12 x 64 lanes x 4 samples staged per wave at most
+#define VAD_WAVES 4
+
+struct VadParams {
+    int32_t L, S, use_sq;
+    int32_t span_vec;       // ceil(((FR - 1) S + L) / 4)
+    int32_t wave_floats;    // per-wave LDS region (floats)
+    int64_t groups_per_utt, total_groups;   // uniform batches
+    const int32_t* group_off;               // ragged: [B+1] prefix of ceil(T_b / FR)
+    const int32_t* group_utt;
+};
+
+// ACC: 0 = fp32 partial sums of |x| (exact for int16 input), 1 = fp64 sums of |x|, 2 = fp64 sums of x^2
+template <int DTYPE, int FR, bool RAGGED, int ACC>
+__global__ __launch_bounds__(64 * VAD_WAVES) void vad_tile_kernel(VadParams P, BatchGeom bg,
+                                                                  const void* __restrict__ wave,
+                                                                  double* __restrict__ amp_sum,
+                                                                  int32_t* __restrict__ zcr) {
+    constexpr int LPF = 64 / FR;   // lanes per frame
+    constexpr int SHIFT = FR == 16 ? 4 : (FR == 8 ? 3 : 2);
+    static_assert(FR == 16 || FR == 8 || FR == 4, "");
+    extern __shared__ __attribute__((aligned(256))) float smem_f[];
+    const int tid = threadIdx.x;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    float* wbuf = smem_f + wid * P.wave_floats;
+    const int total_groups = RAGGED ? P.group_off[bg.n_utt] : (int)P.total_groups;
+    const int gstride = (int)gridDim.x * VAD_WAVES;
+    const int f = lane / LPF, q = lane % LPF;
+    const int L = P.L, S = P.S;
+    const int Lr = (L + LPF - 1) / LPF * LPF;            // walk length, multiple of LPF
+    const int rot = ((LPF * f - S * f) % 64 + 64) % 64;   // (S f + rot) % 64 == LPF f: disjoint banks
+
+    for (int G = __builtin_amdgcn_readfirstlane((int)blockIdx.x * VAD_WAVES + wid); G < total_groups; G += gstride) {
+        int utt, t0, T, nsamp;
+        int64_t s0, row0;
+        if constexpr (RAGGED) {
+            utt = P.group_utt[G];
+            t0 = (G - P.group_off[utt]) << SHIFT;
+            s0 = bg.sample_off[utt];
+            nsamp = (int)(bg.sample_off[utt + 1] - s0);
+            row0 = bg.frame_off[utt];
+            T = (int)(bg.frame_off[utt + 1] - row0);
+        } else {
+            const int gpu = (int)P.groups_per_utt;
+            utt = G / gpu;
+            t0 = (G - utt * gpu) << SHIFT;
+            nsamp = (int)bg.uniform_samples;
+            T = (int)bg.uniform_frames;
+            s0 = (int64_t)utt * bg.uniform_samples;
+            row0 = (int64_t)utt * bg.uniform_frames;
+        }
+        const int base = t0 * S;
+        const int64_t g0 = s0 + base;
+        const int d = RAGGED ? (int)(g0 & 3) : 0;
+        {
+            const int64_t a0 = g0 - d;
+            const int span_vec = RAGGED ? P.span_vec + 1 : P.span_vec;
+            F512Raw<DTYPE> raw[VAD_NSTAGE];
+#pragma unroll
+            for (int r = 0; r < VAD_NSTAGE; ++r) {
+                const int v = lane + 64 * r;
+                const int rel = base - d + 4 * v;
+                const bool touch = v < span_vec && rel + 3 >= 0 && rel < nsamp;
+                raw[r] = f512_load_raw<DTYPE>(wave, touch ? a0 + 4 * v : 0);
+            }
+#pragma unroll
+            for (int r = 0; r < VAD_NSTAGE; ++r) {
+                const int v = lane + 64 * r;
+                const int rel = base - d + 4 * v;
+                float x[4];
+                f512_unpack<DTYPE>(raw[r], x);
+                float4 y = make_float4(x[0], x[1], x[2], x[3]);
+                if (rel + 0 < 0 || rel + 0 >= nsamp) y.x = 0.f;   // zero padding of the last frame (sigproc.py:84-87)
+                if (rel + 1 < 0 || rel + 1 >= nsamp) y.y = 0.f;
+                if (rel + 2 < 0 || rel + 2 >= nsamp) y.z = 0.f;
+                if (rel + 3 < 0 || rel + 3 >= nsamp) y.w = 0.f;
+                if (v < span_vec) *reinterpret_cast<float4*>(wbuf + 4 * v) = y;
+            }
+        }
+        F512_FENCE();
+
+        const float* fr = wbuf + d + f * S;
+        double acc = 0.0;
+        int32_t cnt = 0;
+        float accf = 0.f;
+        const int last = L - 1;
+        // eight steps at a time: all sixteen LDS reads are issued before the first use; no branches
+        // (addresses are clamped, contributions masked; element L - 1 has no right neighbour)
+        for (int j0 = 0; j0 < Lr; j0 += 8 * LPF) {
+            float av[8], bv[8];
+            int iv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u * LPF;
+                int i = q + j + rot;
+                if (i >= Lr) i -= Lr;
+                if (j >= Lr) i = L;                       // step past the walk: masked below
+                iv[u] = i;
+                av[u] = fr[min(i, last)];
+                bv[u] = fr[min(i + 1, last)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float a = iv[u] > last ? 0.f : av[u];
+                const float b = bv[u];
+                const uint32_t differ = (__float_as_uint(a) ^ __float_as_uint(b)) >> 31;
+                const uint32_t pair = differ & (uint32_t)(a != 0.f) & (uint32_t)(b != 0.f) & (uint32_t)(iv[u] < last);
+                cnt += (int32_t)pair;
+                if constexpr (ACC == 0) accf += fabsf(a);
+                else if constexpr (ACC == 1) acc += (double)fabsf(a);
+                else acc += (double)a * (double)a;
+            }
+        }
+        if constexpr (ACC == 0) acc = (double)accf;
+#pragma unroll
+        for (int o = LPF / 2; o > 0; o >>= 1) {
+            acc += __shfl_xor(acc, o, 64);
+            cnt += __shfl_xor(cnt, o, 64);
+        }
+        const int t = t0 + f;
+        if (q == 0 && t < T) {
+            amp_sum[row0 + t] = acc;
+            zcr[row0 + t] = cnt;
+        }
+        F512_FENCE();
+    }
+}
+
+// Picks the tile shape; returns 0 if the configuration has to take the one-wave-per-frame kernel.
+static inline int vad_tile_frames(int32_t L, int32_t S) {
+    if (L < 64 || S < 1) return 0;
+    if ((15 * (int64_t)S + L + 3) / 4 + 1 <= 64 * VAD_NSTAGE) return 16;
+    if ((3 * (int64_t)S + L + 3) / 4 + 1 <= 64 * VAD_NSTAGE) return 4;
+    return 0;
+}
+
+static inline bool vad_tile_applicable(const BatchGeom& bg, const void* d_wave, int dtype, int FR) {
+    if (FR == 0) return false;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(d_wave);
+    if ((a % (dtype == DSP_WAVE_I16 ? 8 : 16)) != 0) return false;
+    if (bg.uniform_samples > 0) {
+        if ((bg.uniform_samples % 4) != 0) return false;
+        return bg.uniform_samples <= 0x3fffffff && ((bg.uniform_frames + FR - 1) / FR) * bg.n_utt <= 0x3fffffff;
+    }
+    return bg.total_frames / FR + bg.n_utt <= 0x3fffffff;
+}
+
+template <int DTYPE, int FR, bool RAGGED>
+static int vad_tile_launch_k(const VadParams& P, const BatchGeom& bg, const void* d_wave, double* d_amp,
+                             int32_t* d_zcr, int64_t groups_bound, hipStream_t st) {
+    const size_t lds = (size_t)VAD_WAVES * P.wave_floats * sizeof(float);
+    int64_t blocks = (groups_bound + VAD_WAVES - 1) / VAD_WAVES;
+    const int64_t cap = 256 * 3;   // <= 48 KB per workgroup: three resident workgroups per CU
+    if (blocks > cap) {
+        const int64_t rounds = (blocks + cap - 1) / cap;
+        blocks = (blocks + rounds - 1) / rounds;
+    }
+    // int16 samples: the |x| sum of one lane stays below 2^24, so fp32 partial sums are exact
+    const bool f32_exact = DTYPE == DSP_WAVE_I16 && !P.use_sq && (P.L + 64 / FR - 1) / (64 / FR) < 512;
+    if (f32_exact)
+        vad_tile_kernel<DTYPE, FR, RAGGED, 0><<<(int)blocks, 64 * VAD_WAVES, lds, st>>>(P, bg, d_wave, d_amp, d_zcr);
+    else if (!P.use_sq)
+        vad_tile_kernel<DTYPE, FR, RAGGED, 1><<<(int)blocks, 64 * VAD_WAVES, lds, st>>>(P, bg, d_wave, d_amp, d_zcr);
+    else
+        vad_tile_kernel<DTYPE, FR, RAGGED, 2><<<(int)blocks, 64 * VAD_WAVES, lds, st>>>(P, bg, d_wave, d_amp, d_zcr);
+    return hipGetLastError() == hipSuccess ? DSP_OK : DSP_EHIP;
+}
+
+template <int FR>
+static int vad_tile_launch_t(VadParams P, const BatchGeom& bg, const void* d_wave, int dtype, double* d_amp,
+                             int32_t* d_zcr, hipStream_t st) {
+    P.span_vec = ((FR - 1) * P.S + P.L + 3) / 4;
+    P.wave_floats = (4 * (P.span_vec + 1) + 63) / 64 * 64;
+    constexpr int SHIFT = FR == 16 ? 4 : 2;
+    if (bg.uniform_samples > 0) {
+        P.groups_per_utt = (bg.uniform_frames + FR - 1) / FR;
+        P.total_groups = P.groups_per_utt * bg.n_utt;
+        if (dtype == DSP_WAVE_I16)
+            return vad_tile_launch_k<DSP_WAVE_I16, FR, false>(P, bg, d_wave, d_amp, d_zcr, P.total_groups, st);
+        return vad_tile_launch_k<DSP_WAVE_F32, FR, false>(P, bg, d_wave, d_amp, d_zcr, P.total_groups, st);
+    }
+    const int64_t bound = bg.total_frames / FR + bg.n_utt;
+    const size_t ws_bytes = ((size_t)bg.n_utt + 1 + (size_t)bound) * sizeof(int32_t);
+    DspWorkspace* w = dsp_workspace_pool().acquire(ws_bytes);
+    if (!w) return DSP_EHIP;
+    int32_t* group_off = static_cast<int32_t*>(w->ptr);
+    int32_t* group_utt = group_off + bg.n_utt + 1;
+    f512_group_prefix_kernel<<<1, 1024, 0, st>>>(bg.frame_off, bg.n_utt, SHIFT, group_off);
+    const int fill_blocks = (int)((bg.n_utt + 255) / 256 < 1024 ? (bg.n_utt + 255) / 256 : 1024);
+    f512_group_fill_kernel<<<fill_blocks, 256, 0, st>>>(group_off, bg.n_utt, group_utt);
+    P.group_off = group_off;
+    P.group_utt = group_utt;
+    int rc;
+    if (dtype == DSP_WAVE_I16)
+        rc = vad_tile_launch_k<DSP_WAVE_I16, FR, true>(P, bg, d_wave, d_amp, d_zcr, bound, st);
+    else
+        rc = vad_tile_launch_k<DSP_WAVE_F32, FR, true>(P, bg, d_wave, d_amp, d_zcr, bound, st);
+    if (dsp_workspace_pool().release(w, st) != 0 && rc == DSP_OK) rc = DSP_EHIP;
+    return rc;
+}
+
+static inline int vad_tile_launch(int FR, int32_t L, int32_t S, int32_t use_sq, const BatchGeom& bg, const void* d_wave,
+                                  int dtype, double* d_amp, int32_t* d_zcr, hipStream_t st) {
+    VadParams P;
+    memset(&P, 0, sizeof(P));
+    P.L = L; P.S = S; P.use_sq = use_sq;
+    if (FR == 16) return vad_tile_launch_t<16>(P, bg, d_wave, dtype, d_amp, d_zcr, st);
+    return vad_tile_launch_t<4>(P, bg, d_wave, dtype, d_amp, d_zcr, st);
+}

@@ -173,6 +173,43 @@ def test_endpoint_batch_matches_single():
         assert tuple(got[b]) == dsp_oracle.basic_endpoint_detection(c, 16000)
 
 
+@pytest.mark.parametrize('rate', [16000, 48000, 22050, 1600])
+@pytest.mark.parametrize('dtype', [np.int16, np.float32])
+def test_vad_tile_kernel_vs_per_frame_kernel_and_oracle(rate, dtype):
+    """The tiled amplitude / ZCR kernel (16 or 4 frames per wave) against the one-wave-per-frame
+    kernel (dsp_debug_force_generic) and the oracle, dense and ragged.  int16: every value exact.
+    rate 22050 gives L=661, S=220 (odd sizes), rate 1600 gives L=48 < 64 (no tile kernel)."""
+    from features.batch import EndpointPlan
+    from features import _native as nat
+    ep = EndpointPlan(rate, 0.03, 0.01)
+    rng = np.random.default_rng(91)
+    lens = [rate, rate // 3 + 1, ep.L, ep.L - 1, 1, 2 * rate + 3, ep.L + 1, 5 * ep.S + 7]
+    so = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    flat = _batch(92, 1, int(so[-1]), dtype=dtype)[0]
+    flat[rng.integers(0, len(flat), len(flat) // 10)] = 0          # exact zeros never count as crossings
+    dense = _batch(93, 6, (rate // 2) // 4 * 4, dtype=dtype)
+    results = {}
+    for mode in (0, 1):
+        try:
+            nat.check(nat.load().dsp_debug_force_generic(mode))
+            _, amp_r, zcr_r, fo_r = ep.detect_batch(flat, sample_offsets=so, return_feature=True)
+            _, amp_d, zcr_d, fo_d = ep.detect_batch(dense, return_feature=True)
+            results[mode] = (amp_r.copy(), zcr_r.copy(), amp_d.copy(), zcr_d.copy())
+        finally:
+            nat.check(nat.load().dsp_debug_force_generic(0))
+    tile, per = results[0], results[1]
+    assert np.array_equal(tile[1], per[1]) and np.array_equal(tile[3], per[3])       # ZCR: integers
+    if dtype == np.int16:
+        assert np.array_equal(tile[0], per[0]) and np.array_equal(tile[2], per[2])   # sums of integers: exact
+    else:
+        assert np.allclose(tile[0], per[0], rtol=1e-12, atol=0) and np.allclose(tile[2], per[2], rtol=1e-12, atol=0)
+    for b in range(len(lens)):
+        frames = dsp_oracle.to_frames(flat[so[b]:so[b + 1]].astype(np.float64), rate, t=0.03, step=0.01)
+        assert fo_r[b + 1] - fo_r[b] == frames.shape[0]
+        assert np.allclose(tile[0][fo_r[b]:fo_r[b + 1]], dsp_oracle.get_amplitude(frames), rtol=1e-6, atol=1e-9)
+        assert list(tile[1][fo_r[b]:fo_r[b + 1]]) == list(dsp_oracle.get_zcr(frames))
+
+
 @pytest.mark.parametrize('unit_variance', [False, True])
 def test_config4_vad_trim_mfcc_pipeline(unit_variance):
     """configs[3]: endpointing -> trim (-> unit variance, model.py:63) -> MFCC+delta+delta2 with

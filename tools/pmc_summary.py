@@ -11,7 +11,7 @@ for d in sys.argv[1:]:
         for r in csv.DictReader(open(f)):
             acc[r['Kernel_Name'][:48]][r['Counter_Name']].append(float(r['Counter_Value']))
         for k, v in acc.items():
-            if 'mfcc512' not in k and 'delta' not in k and 'generic' not in k:
+            if not any(t in k for t in ('mfcc', 'delta', 'generic', 'vad', 'endpoint', 'trim')):
                 continue
             n = len(next(iter(v.values())))
             print(f'{d} | {k} | n={n}')
