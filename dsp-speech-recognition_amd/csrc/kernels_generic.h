@@ -382,9 +382,10 @@ __global__ __launch_bounds__(256) void vad_features_kernel(const void* __restric
 
 // endpoint.amplitude_rule (endpoint.py:133-179, use_acr=False): only the first segment's start and
 // the last segment's end are consumed by basic_endpoint_detection (endpoint.py:43,49).
-__device__ inline void amplitude_rule_dev(const double* amp, int64_t T, double inv_L, double mh,
-                                          double th, int n_l, int n_r, double sigma, double cfg_frame,
-                                          double* sil, int64_t& left, int64_t& right) {
+template <typename AmpT, typename SilT>
+__device__ __forceinline__ void amplitude_rule_dev(AmpT amp, int64_t T, double inv_L, double mh,
+                                                   double th, int n_l, int n_r, double sigma, double cfg_frame,
+                                                   SilT sil, int64_t& left, int64_t& right) {
     int ns = 0;
     const int64_t cl = n_l < T ? n_l : T;                   // amp[:n_l]
     for (int64_t i = 0; i < cl; ++i) sil[ns++] = amp[i] * inv_L;
@@ -429,6 +430,31 @@ __device__ inline void amplitude_rule_dev(const double* amp, int64_t T, double i
     if (!any) { left = 0; right = T; }
 }
 
+template <typename AmpT, typename ZcrT, typename SilT>
+__device__ __forceinline__ void endpoint_rule_body(AmpT amp, ZcrT z, SilT sil, int64_t T, double inv_L,
+                                                   double cfg_frame, double cfg_step, int32_t* __restrict__ out2) {
+    const int n_sil = (int)(0.100 / cfg_step);              // int(l_sil / cfg.step), endpoint.py:151
+    int64_t left = 0, right = T;
+    amplitude_rule_dev(amp, T, inv_L, 0.25, 0.100, n_sil, n_sil, 3.0, cfg_frame, sil, left, right);
+    if (right - left < 50)                                  // endpoint.py:44-45
+        amplitude_rule_dev(amp, T, inv_L, 0.125, 0.100, n_sil, n_sil, 3.0, cfg_frame, sil, left, right);
+    // zcr_rule, endpoint.py:201-220 (l_sil = 0 -> front slice empty; r_sil = 0.1)
+    const double max_shift = 0.400 / cfg_frame;
+    const int64_t cr = (n_sil == 0 || n_sil > T) ? T : n_sil;
+    double mu = 0.0, var = 0.0;
+    for (int64_t i = T - cr; i < T; ++i) mu += (double)z[i];
+    mu /= (double)cr;
+    for (int64_t i = T - cr; i < T; ++i) var += ((double)z[i] - mu) * ((double)z[i] - mu);
+    const double thres = mu + 3.0 * sqrt(var / (double)cr);
+    int64_t j = left;
+    while (j > 0 && (double)(left - j) <= max_shift && (double)z[j] > thres) --j;
+    int64_t k = right;
+    while (k < T && (double)(k - right) <= max_shift && (double)z[k] > thres) ++k;
+    if (k - j < 50) { j = 0; k = T; }                       // endpoint.py:60-62
+    out2[0] = (int32_t)j;
+    out2[1] = (int32_t)k;
+}
+
 #define DSP_RULE_LDS_FRAMES 2048   // utterances up to this many frames are scanned out of LDS
 
 // One wavefront per utterance: the wave copies the utterance's amp / zcr rows into LDS (coalesced),
@@ -448,38 +474,20 @@ __global__ __launch_bounds__(64) void endpoint_rule_kernel(const double* __restr
     const int64_t T = frame_off[b + 1] - base;
     const double* amp = amp_sum + base;
     const int32_t* z = zcr + base;
+    const double inv_L = 1.0 / (double)L;
     if (T <= DSP_RULE_LDS_FRAMES) {
         for (int i = threadIdx.x; i < (int)T; i += 64) {
-            s_amp[i] = amp[i];
+            s_amp[i] = amp[i] * inv_L;   // the per-frame mean, scaled once instead of at every use
             s_zcr[i] = z[i];
         }
         __syncthreads();
-        amp = s_amp;
-        z = s_zcr;
+        if (threadIdx.x != 0) return;
+        // arrays passed by name: the scans compile to ds_read, not flat loads
+        endpoint_rule_body(s_amp, s_zcr, s_sil, T, 1.0, cfg_frame, cfg_step, endpoints + 2 * b);
+    } else {
+        if (threadIdx.x != 0) return;
+        endpoint_rule_body(amp, z, s_sil, T, inv_L, cfg_frame, cfg_step, endpoints + 2 * b);
     }
-    if (threadIdx.x != 0) return;
-    double* sil = s_sil;
-    const double inv_L = 1.0 / (double)L;
-    const int n_sil = (int)(0.100 / cfg_step);              // int(l_sil / cfg.step), endpoint.py:151
-    int64_t left = 0, right = T;
-    amplitude_rule_dev(amp, T, inv_L, 0.25, 0.100, n_sil, n_sil, 3.0, cfg_frame, sil, left, right);
-    if (right - left < 50)                                  // endpoint.py:44-45
-        amplitude_rule_dev(amp, T, inv_L, 0.125, 0.100, n_sil, n_sil, 3.0, cfg_frame, sil, left, right);
-    // zcr_rule, endpoint.py:201-220 (l_sil = 0 -> front slice empty; r_sil = 0.1)
-    const double max_shift = 0.400 / cfg_frame;
-    const int64_t cr = (n_sil == 0 || n_sil > T) ? T : n_sil;
-    double mu = 0.0, var = 0.0;
-    for (int64_t i = T - cr; i < T; ++i) mu += (double)z[i];
-    mu /= (double)cr;
-    for (int64_t i = T - cr; i < T; ++i) var += ((double)z[i] - mu) * ((double)z[i] - mu);
-    const double thres = mu + 3.0 * sqrt(var / (double)cr);
-    int64_t j = left;
-    while (j > 0 && (double)(left - j) <= max_shift && (double)z[j] > thres) --j;
-    int64_t k = right;
-    while (k < T && (double)(k - right) <= max_shift && (double)z[k] > thres) ++k;
-    if (k - j < 50) { j = 0; k = T; }                       // endpoint.py:60-62
-    endpoints[2 * b] = (int32_t)j;
-    endpoints[2 * b + 1] = (int32_t)k;
 }
 
 // Endpoint-trimmed copy of a ragged batch (model.py:52-64 without augmentation): utterance b keeps
