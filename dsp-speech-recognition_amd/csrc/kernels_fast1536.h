@@ -26,6 +26,9 @@
 #define F1536_PS_STRIDE 776    // 769 bins + padding; == 8 (mod 64)
 #define F1536_XSTRIDE 544      // exchange buffer per frame: 16 rows x 32 floats + 32 (bank offset)
 #define F1536_MAX_NI 4
+#define F1536_SLOTS 64         // mel work items per wave (one per lane)
+#define F1536_PIECES 8         // a filter is cut into at most this many slots
+#define F1536_PART_STRIDE 72   // 64 partial sums + the always-zero slot + padding, per frame
 #ifndef F1536_WAVES
 #define F1536_WAVES 8
 #endif
@@ -33,13 +36,14 @@
 struct F1536Params {
     const float* tables;   // device blob copied to LDS by every workgroup
     int32_t tab_floats;
-    int32_t off_w3, off_tw, off_dct, off_melw, off_mels;
-    int32_t melw_row;
+    int32_t off_w3, off_tw, off_dct, off_melw, off_mels, off_pidx;
+    int32_t melw_row;      // floats per mel slot row (odd number of 16-byte units: conflict-free b128)
+    int32_t mel_blocks;    // 8-tap blocks per mel slot
+    int32_t off_part;      // float offset of the partial-sum rows inside the wave region
     int32_t L, S, M, C, append_energy;
     float preemph;
     int32_t span_vec;      // ceil((3 S + 1536) / 4): 16-byte vectors staged per wave
     int32_t wave_floats;   // per-wave LDS region
-    int32_t len[F1536_MAX_NI];
     int64_t groups_per_utt, total_groups;
     const int32_t* group_off;   // ragged: [B+1] prefix of ceil(T_b / 4)
     const int32_t* group_utt;
@@ -272,30 +276,52 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mfcc1536_kernel(F1536Params P, 
         if (energy == 0.f) energy = DSP_EPS_F32;
         F512_FENCE();
 
-        // ---- sparse mel triangles, log: lane c owns filters c + 16 i ----
+        // ---- sparse mel triangles.  The filters are cut into 64 slots of at most 8 * mel_blocks taps
+        //      (wide filters into several); lane s owns slot s for ALL four frames, so a weight is
+        //      read from LDS once per four frames and every lane runs the same number of taps. ----
+        float* part = wbuf + P.off_part;
+        {
+            const float4* wrow = reinterpret_cast<const float4*>(s_melw + lane * P.melw_row);
+            const float* pbase = wbuf + __float_as_int(smem[P.off_mels + lane]);
+            float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+            const int nb = P.mel_blocks;
+            for (int b = 0; b < nb; ++b) {
+                const float4 w0 = wrow[2 * b], w1 = wrow[2 * b + 1];
+                float4 q0[4], q1[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4* pb = reinterpret_cast<const float4*>(pbase + g * F1536_PS_STRIDE);
+                    q0[g] = pb[2 * b];
+                    q1[g] = pb[2 * b + 1];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    a0[g] = fmaf(w0.x, q0[g].x, a0[g]);
+                    a1[g] = fmaf(w0.y, q0[g].y, a1[g]);
+                    a0[g] = fmaf(w0.z, q0[g].z, a0[g]);
+                    a1[g] = fmaf(w0.w, q0[g].w, a1[g]);
+                    a0[g] = fmaf(w1.x, q1[g].x, a0[g]);
+                    a1[g] = fmaf(w1.y, q1[g].y, a1[g]);
+                    a0[g] = fmaf(w1.z, q1[g].z, a0[g]);
+                    a1[g] = fmaf(w1.w, q1[g].w, a1[g]);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) part[g * F1536_PART_STRIDE + lane] = a0[g] + a1[g];
+            if (lane < 4) part[lane * F1536_PART_STRIDE + F1536_SLOTS] = 0.f;   // the "no piece" slot
+        }
+        F512_FENCE();
+        // gather the pieces of this lane's filters (c + 16 i) of its own frame, log
         float lm[NI];
         {
-            const float4* wrow = reinterpret_cast<const float4*>(s_melw + c * P.melw_row);
+            const float* pf = part + f * F1536_PART_STRIDE;
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                const float4* pb = reinterpret_cast<const float4*>(ps + __float_as_int(smem[P.off_mels + i * 16 + c]));
-                float acc0 = 0.f, acc1 = 0.f;
-                const int nb = P.len[i] >> 3;
-                for (int b = 0; b < nb; ++b) {
-                    const float4 w0 = wrow[2 * b], w1 = wrow[2 * b + 1];
-                    const float4 q0 = pb[2 * b], q1 = pb[2 * b + 1];
-                    __builtin_amdgcn_sched_barrier(0);
-                    acc0 = fmaf(w0.x, q0.x, acc0);
-                    acc1 = fmaf(w0.y, q0.y, acc1);
-                    acc0 = fmaf(w0.z, q0.z, acc0);
-                    acc1 = fmaf(w0.w, q0.w, acc1);
-                    acc0 = fmaf(w1.x, q1.x, acc0);
-                    acc1 = fmaf(w1.y, q1.y, acc1);
-                    acc0 = fmaf(w1.z, q1.z, acc0);
-                    acc1 = fmaf(w1.w, q1.w, acc1);
-                }
-                wrow += 2 * nb;
-                float acc = acc0 + acc1;
+                const int4* px = reinterpret_cast<const int4*>(smem + P.off_pidx + (i * 16 + c) * F1536_PIECES);
+                const int4 x0 = px[0], x1 = px[1];
+                float acc = (pf[x0.x] + pf[x0.y]) + (pf[x0.z] + pf[x0.w]);
+                acc += (pf[x1.x] + pf[x1.y]) + (pf[x1.z] + pf[x1.w]);
                 if (acc == 0.f) acc = DSP_EPS_F32;
                 lm[i] = __logf(acc);
             }
@@ -375,62 +401,55 @@ static inline int fast1536_plan_init(dsp_plan* p, const dsp_plan_desc* d, const 
             if (j >= M) continue;
             for (int k = 0; k < C; ++k) dct[((size_t)i * 16 + c) * 20 + k] = d->h_dct[(size_t)k * M + j];
         }
-    // mel: one weight row per lane (filter groups back to back), every filter read from a bin that is
-    // a multiple of 4, every group padded to a multiple of 8 taps; padded reads stay inside the row.
-    // A filter whose padded read would cross the end of the row is read from an earlier start
-    // (more leading zero weights), which may lengthen the group: iterate to the fixed point.
-    auto placed_start = [](int mel_start, int len) {
-        int start = mel_start & ~3;
-        if (start + len > F1536_PS_STRIDE) start = (F1536_PS_STRIDE - len) & ~3;
-        return start;
-    };
+    // mel: cut the filters into at most 64 slots of `cap` taps (cap a multiple of 8, as small as
+    // possible).  A slot is read from a bin that is a multiple of 4 (leading zero weights absorb the
+    // misalignment) and never runs past the end of the 776-float spectrum row.
     bool ok = true;
-    int row_floats = 0;
-    for (int i = 0; i < NI; ++i) {
-        int len = 8;
-        for (int it = 0; it < 8; ++it) {
-            int need = 0;
-            for (int c = 0; c < 16; ++c) {
-                const int j = c + 16 * i;
-                if (j >= M) continue;
-                const int n = d->h_mel_start[j] - placed_start(d->h_mel_start[j], len) + d->h_mel_count[j];
-                if (n > need) need = n;
-            }
-            need = (need + 7) / 8 * 8;
-            if (need <= len) break;
-            len = need;
+    int cap = 0;
+    for (int tryc = 8; tryc <= F1536_PS_STRIDE; tryc += 8) {
+        int n = 0, worst = 0;
+        for (int j = 0; j < M; ++j) {
+            if (d->h_mel_count[j] <= 0) continue;
+            const int span = (d->h_mel_start[j] & 3) + d->h_mel_count[j];
+            const int pcs = (span + tryc - 1) / tryc;
+            n += pcs;
+            if (pcs > worst) worst = pcs;
         }
-        if (len > F1536_PS_STRIDE) ok = false;
-        fp->P.len[i] = len;
-        row_floats += len;
+        if (n <= F1536_SLOTS && worst <= F1536_PIECES) { cap = tryc; break; }
     }
-    int melw_row = row_floats > 0 ? row_floats : 8;
+    if (cap == 0) ok = false;
+    int melw_row = cap > 0 ? cap : 8;
     if (((melw_row / 4) & 1) == 0) melw_row += 4;
-    std::vector<float> melw((size_t)16 * melw_row, 0.f), mels((size_t)NI * 16, 0.f);
-    for (int c = 0; c < 16 && ok; ++c) {
-        int pos = 0;
-        for (int i = 0; i < NI; ++i) {
-            const int j = c + 16 * i, len = fp->P.len[i];
-            int32_t start = 0;
-            if (j < M) {
-                start = placed_start(d->h_mel_start[j], len);
-                const int lead = d->h_mel_start[j] - start;
-                if (start < 0 || lead + d->h_mel_count[j] > len) { ok = false; break; }
-                for (int s2 = 0; s2 < d->h_mel_count[j]; ++s2)
-                    melw[(size_t)c * melw_row + pos + lead + s2] = d->h_mel_weights[mel_off[j] + s2];
+    std::vector<float> melw((size_t)F1536_SLOTS * melw_row, 0.f), mels(F1536_SLOTS, 0.f);
+    std::vector<int32_t> pidx((size_t)NI * 16 * F1536_PIECES, F1536_SLOTS);   // default: the always-zero slot
+    if (ok) {
+        int slot = 0;
+        for (int j = 0; j < M; ++j) {
+            const int ms = d->h_mel_start[j], cnt = d->h_mel_count[j];
+            if (cnt <= 0) continue;
+            const int a0 = ms & ~3;
+            const int pcs = ((ms - a0) + cnt + cap - 1) / cap;
+            for (int pc = 0; pc < pcs; ++pc, ++slot) {
+                const int lo = a0 + pc * cap, hi = lo + cap;            // bins this piece covers
+                int32_t start = lo;
+                if (start + cap > F1536_PS_STRIDE) start = F1536_PS_STRIDE - cap;   // stays a multiple of 4
+                for (int bin = (lo > ms ? lo : ms); bin < hi && bin < ms + cnt; ++bin)
+                    melw[(size_t)slot * melw_row + (bin - start)] = d->h_mel_weights[mel_off[j] + (bin - ms)];
+                memcpy(&mels[slot], &start, 4);
+                pidx[((size_t)(j / 16) * 16 + (j % 16)) * F1536_PIECES + pc] = slot;
             }
-            memcpy(&mels[(size_t)i * 16 + c], &start, 4);
-            pos += len;
         }
     }
     auto pad64 = [](size_t n) { return (n + 63) / 64 * 64; };
     const size_t o_w3 = 1536, o_tw = o_w3 + w3.size(), o_dct = o_tw + tw.size();
     const size_t o_melw = pad64(o_dct + dct.size()), o_mels = o_melw + melw.size();
-    const size_t total = pad64(o_mels + mels.size());
+    const size_t o_pidx = pad64(o_mels + mels.size());
+    const size_t total = pad64(o_pidx + pidx.size());
     size_t wave_floats = 4 * F1536_PS_STRIDE;
     if ((size_t)4 * (span_vec + 1) > wave_floats) wave_floats = (size_t)4 * (span_vec + 1);
     if ((size_t)4 * F1536_XSTRIDE > wave_floats) wave_floats = 4 * F1536_XSTRIDE;
-    wave_floats = pad64(wave_floats);
+    const size_t off_part = pad64(wave_floats);       // partial sums live behind the spectrum rows
+    wave_floats = pad64(off_part + 4 * F1536_PART_STRIDE);
     if (!ok || (total + F1536_WAVES * wave_floats) * 4 > 160 * 1024) {  // does not fit one CU's LDS: generic kernel
         delete fp;
         return DSP_OK;
@@ -442,6 +461,7 @@ static inline int fast1536_plan_init(dsp_plan* p, const dsp_plan_desc* d, const 
     memcpy(blob.data() + o_dct, dct.data(), dct.size() * 4);
     memcpy(blob.data() + o_melw, melw.data(), melw.size() * 4);
     memcpy(blob.data() + o_mels, mels.data(), mels.size() * 4);
+    memcpy(blob.data() + o_pidx, pidx.data(), pidx.size() * 4);
     if (hipMalloc(reinterpret_cast<void**>(&fp->d_tables), total * 4) != hipSuccess ||
         hipMemcpy(fp->d_tables, blob.data(), total * 4, hipMemcpyHostToDevice) != hipSuccess) {
         if (fp->d_tables) (void)hipFree(fp->d_tables);
@@ -452,6 +472,7 @@ static inline int fast1536_plan_init(dsp_plan* p, const dsp_plan_desc* d, const 
     fp->P.tab_floats = (int32_t)total;
     fp->P.off_w3 = (int32_t)o_w3; fp->P.off_tw = (int32_t)o_tw; fp->P.off_dct = (int32_t)o_dct;
     fp->P.off_melw = (int32_t)o_melw; fp->P.off_mels = (int32_t)o_mels; fp->P.melw_row = melw_row;
+    fp->P.off_pidx = (int32_t)o_pidx; fp->P.mel_blocks = cap / 8; fp->P.off_part = (int32_t)off_part;
     fp->P.L = L; fp->P.S = d->frame_step; fp->P.M = M; fp->P.C = C;
     fp->P.append_energy = d->append_energy ? 1 : 0;
     fp->P.preemph = d->preemph;

@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 import threading
 
 import numpy as np
@@ -70,6 +71,34 @@ class DspError(RuntimeError):
     pass
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.
+
+    PyTorch-ROCm wheels bundle their own ``libamdhip64.so`` (SONAME ``libamdhip64.so.7``) but link
+    to it under the unversioned name, so the loader does not recognise a system runtime that is
+    already mapped: a process that loads this library first and imports torch later would end up
+    with two HIP runtimes, and the second one finds no GPU ("No HIP GPUs are available").  When
+    torch is installed but not imported yet, map ITS runtime first (without importing torch); our
+    library's ``libamdhip64.so.7`` dependency then binds to it by SONAME, which is also what
+    happens when torch is imported first.  ``DSP_HIP_RUNTIME=system`` keeps the system runtime.
+    """
+    if 'torch' in sys.modules or os.environ.get('DSP_HIP_RUNTIME', 'auto') == 'system':
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), 'lib', 'libamdhip64.so')
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass            # fall back to whatever the dynamic loader finds
+
+
 def load():
     """Load the shared library (no GPU needed for this step) and declare every signature."""
     global _lib
@@ -82,6 +111,7 @@ def load():
             raise DspError(
                 f'{LIB_PATH} not found: build it with `python __graft_entry__.py` (or make -C '
                 f'dsp-speech-recognition_amd/csrc). There is no CPU fallback.')
+        _share_hip_runtime_with_torch()
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
