@@ -132,6 +132,79 @@ __device__ __forceinline__ void f1536_cfft512(cpx (&z)[32], float* __restrict__ 
     for (int k = 0; k < 16; ++k) pb[k] = scale * fmaf(u[k].x, u[k].x, u[k].y * u[k].y);
 }
 
+// Real 512-point FFT of one frame spread over its 16 lanes.  In: r[n1] = y[16 n1 + c] (real).
+// Column pass: FFT16 of r[2m] + i r[2m+1], untangled to the 17 rows k1 = 0..16 of the real-input
+// FFT32 (rows 17..31 are their mirror images and never materialise).  Rows 0..15 go through the
+// exchange and one FFT16 per lane; row 16 sits in the spare 17th row of the exchange buffer and is
+// transformed by lane 0 alone.  All values carry a factor 2 (folded into `scale`).
+// Out: pa[k2] = |Y[c + 32 k2]|^2 (lane c; k2 >= 8 are the mirror bins 512 - c - 32 k2 for c >= 1),
+//      p16[k2] = |Y[16 + 32 k2]|^2 for k2 < 8 (valid in lane 0 only).
+__device__ __forceinline__ void f1536_rfft512(const float (&r)[32], float* __restrict__ xb,
+                                              const float2* __restrict__ s_tw, int c, float scale,
+                                              float (&pa)[16], float (&p16)[8]) {
+    cpx g[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) g[m] = {r[2 * m], r[2 * m + 1]};
+    FFTReg<16>::run(g);
+    cpx R[17];
+    R[0] = {2.f * (g[0].x + g[0].y), 0.f};
+    R[16] = {2.f * (g[0].x - g[0].y), 0.f};
+    R[8] = {2.f * g[8].x, -2.f * g[8].y};
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        const cpx a = g[k], b = g[16 - k];
+        const cpx e = {a.x + b.x, a.y - b.y};             // A + conj(B)
+        const cpx dd = {a.x - b.x, a.y + b.y};            // A - conj(B)
+        const cpx o = {dd.y, -dd.x};                      // -i (A - conj(B))
+        const cpx t = cmulc(o, DSP_COS32[k], -DSP_SIN32[k]);   // W32^k * o
+        R[k] = {e.x + t.x, e.y + t.y};
+        R[16 - k] = {e.x - t.x, t.y - e.y};               // conj(e - t)
+    }
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) {
+        const float2 t = s_tw[(k1 - 1) * 16 + c];
+        R[k1] = cmulc(R[k1], t.x, t.y);
+    }
+    {
+        const float2 t = s_tw[15 * 16 + c];               // row 16 is real before the twiddle
+        R[16] = {R[16].x * t.x, R[16].x * t.y};
+    }
+    float* wr = xb + 2 * (c & 1);
+    const int ch = c >> 1;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr)
+        *reinterpret_cast<float2*>(wr + rr * 32 + 4 * (ch ^ (rr >> 1))) = make_float2(R[rr].x, R[rr].y);
+    *reinterpret_cast<float2*>(wr + 16 * 32 + 4 * ch) = make_float2(R[16].x, R[16].y);
+    F512_FENCE();
+    cpx u[16];
+    const float* rd = xb + c * 32;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float4 t = *reinterpret_cast<const float4*>(rd + 4 * (i ^ ch));
+        u[2 * i] = {t.x, t.y};
+        u[2 * i + 1] = {t.z, t.w};
+    }
+    F512_FENCE();
+    FFTReg<16>::run(u);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) pa[k] = scale * fmaf(u[k].x, u[k].x, u[k].y * u[k].y);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p16[k] = 0.f;
+    if (c == 0) {
+        cpx v[16];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float4 t = *reinterpret_cast<const float4*>(xb + 16 * 32 + 4 * i);
+            v[2 * i] = {t.x, t.y};
+            v[2 * i + 1] = {t.z, t.w};
+        }
+        FFTReg<16>::run(v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p16[k] = scale * fmaf(v[k].x, v[k].x, v[k].y * v[k].y);
+    }
+    F512_FENCE();
+}
+
 template <int NI, int NC, int NSTAGE, int DTYPE, int WAVES, bool RAGGED>
 __global__ __launch_bounds__(64 * WAVES, 2) void mfcc1536_kernel(F1536Params P, BatchGeom bg,
                                                                  const void* __restrict__ wave,
@@ -234,15 +307,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mfcc1536_kernel(F1536Params P, 
 
         constexpr float SC = 1.0f / 1536.0f;
         float* xb = wbuf + f * F1536_XSTRIDE;
-        float p1a[16], p1b[16], p0a[16], p0b[16];
+        float p1a[16], p1b[16], p0a[16], p016[8];
         f1536_cfft512(y1, xb, s_tw, c, SC, p1a, p1b);
         F512_FENCE();
-        {
-            cpx z[32];
-#pragma unroll
-            for (int n1 = 0; n1 < 32; ++n1) z[n1] = {y0[n1], 0.f};
-            f1536_cfft512(z, xb, s_tw, c, SC, p0a, p0b);
-        }
+        f1536_rfft512(y0, xb, s_tw, c, 0.25f * SC, p0a, p016);
         F512_FENCE();
 
         // ---- power spectrum -> LDS row of this frame (every bin written exactly once) ----
@@ -253,10 +321,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mfcc1536_kernel(F1536Params P, 
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 q[96 * k] = p0a[k];                    // bin 3 (c + 32 k)
-                q[48 + 96 * k] = p0b[k];               // bin 3 (16 + c + 32 k)
                 q[1 + 96 * k] = p1a[k];                // bin 3 (c + 32 k) + 1
                 q[49 + 96 * k] = p1b[k];               // bin 3 (16 + c + 32 k) + 1
-                energy += (p0a[k] + p0b[k]) + (p1a[k] + p1b[k]);
+                energy += p0a[k] + (p1a[k] + p1b[k]);
             }
             float* m = ps - 3 * c;
 #pragma unroll
@@ -266,10 +333,22 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mfcc1536_kernel(F1536Params P, 
                 energy += p1a[k] + p1b[k];
             }
             if (c == 0) {
+                // lane 0: row 0 gives bins 96 k (k <= 8; its k >= 9 are duplicates), row 16 bins 48 + 96 k
                 ps[768] = p0a[8];
                 energy += p0a[8];
-            } else if (c < 8) {
-                ps[768 + c] = 0.f;                     // row padding read by zero-weight mel taps
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    ps[48 + 96 * k] = p016[k];
+                    energy += p016[k];
+                }
+            } else {
+                // rows 1..15: outputs k >= 8 are the mirror bins 3 (512 - c - 32 k) = residues 17..31
+#pragma unroll
+                for (int k = 8; k < 16; ++k) {
+                    m[1536 - 96 * k] = p0a[k];
+                    energy += p0a[k];
+                }
+                if (c < 8) ps[768 + c] = 0.f;          // row padding read by zero-weight mel taps
             }
         }
         energy = frame16_allreduce(energy);
