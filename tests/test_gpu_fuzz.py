@@ -1,0 +1,73 @@
+"""Seeded random configurations: the specialised kernels (NFFT 512 and 1536) against the generic
+table-driven kernel on the same ragged and dense batches.  The two are independent implementations
+of the reference path (sigproc.py:66-185, base.py:8-79), so agreement on shapes nobody hand-picked
+-- 1-filter banks, 1 cepstrum, tiny hops, odd lengths, band limits -- guards the table builders."""
+import numpy as np
+import pytest
+
+from conftest import normwise
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_cfg(rng, nfft):
+    rate = int(rng.choice([8000, 16000, 22050, 44100, 48000]))
+    if nfft == 512:
+        L = int(rng.integers(16, 513))
+        S = 2 * int(rng.integers(1, 115))          # even hop, 7 S + 512 fits the wave buffer
+        M = int(rng.integers(1, 65))
+    else:
+        L = int(rng.integers(64, 1537))
+        S = int(rng.integers(1, 600))
+        M = int(rng.integers(1, 65))
+    C = int(rng.integers(1, min(M, 16) + 1))
+    low = float(rng.choice([0, 0, 50, 300]))
+    high = None if rng.random() < 0.5 else float(rng.uniform(low + 1000, rate / 2))
+    return dict(samplerate=rate, winlen=(L + 0.25) / rate, winstep=(S + 0.25) / rate, numcep=C, nfilt=M,
+                nfft=nfft, lowfreq=low, highfreq=high, preemph=float(rng.choice([0.0, 0.95, 0.97])),
+                ceplifter=int(rng.choice([0, 22])), appendEnergy=bool(rng.integers(0, 2))), L, S
+
+
+@pytest.mark.parametrize('nfft', [512, 1536])
+def test_random_configs_fast_vs_generic(nfft):
+    from features.batch import FeaturePlan
+    from features import _native as nat
+    lib = nat.load()
+    rng = np.random.default_rng(1000 + nfft)
+    n_fast, worst = 0, 0.0
+    for trial in range(40):
+        cfg, L, S = _random_cfg(rng, nfft)
+        try:
+            plan = FeaturePlan(winfunc=np.hamming if trial % 2 else np.hanning, **cfg)
+        except AssertionError:
+            continue                                 # highfreq > rate / 2 after rounding: reference asserts too
+        assert (plan.L, plan.S) == (L, S)
+        if not lib.dsp_plan_has_fast_path(plan.plan.handle):
+            continue
+        n_fast += 1
+        dtype = np.int16 if trial % 3 == 0 else np.float32
+        lens = [int(x) for x in rng.integers(1, 6 * L + 7 * S, 9)] + [L, L + 1, 1]
+        so = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+        if dtype == np.int16:
+            flat = np.clip(np.round(3000 * rng.standard_normal(so[-1])), -32768, 32767).astype(np.int16)
+        else:
+            flat = (0.25 * rng.standard_normal(so[-1])).astype(np.float32)
+        n_dense = (3 * L + 5 * S) // 4 * 4
+        dense = flat[:5 * n_dense].reshape(5, n_dense) if len(flat) >= 5 * n_dense else None
+        got_r, fo = plan.mfcc_batch(flat, sample_offsets=so, delta_n=1)
+        got_d = plan.mfcc_batch(dense, delta_n=1)[0] if dense is not None else None
+        try:
+            nat.check(lib.dsp_debug_force_generic(1))
+            ref_r, _ = plan.mfcc_batch(flat, sample_offsets=so, delta_n=1)
+            ref_d = plan.mfcc_batch(dense, delta_n=1)[0] if dense is not None else None
+        finally:
+            nat.check(lib.dsp_debug_force_generic(0))
+        assert np.isfinite(got_r).all(), (trial, cfg)
+        # two fp32 pipelines; observed worst case 3.2e-5 (NFFT 512) and 1.3e-6 (NFFT 1536)
+        tol = 1e-4
+        worst = max(worst, normwise(got_r, ref_r))
+        assert normwise(got_r, ref_r) <= tol, (trial, cfg, normwise(got_r, ref_r))
+        if dense is not None:
+            assert normwise(got_d, ref_d) <= tol, (trial, cfg, 'dense', normwise(got_d, ref_d))
+    assert n_fast >= 15, n_fast
+    print(f'nfft={nfft}: {n_fast} configurations on the fast path, worst normwise {worst:.2e}')
