@@ -71,3 +71,33 @@ def test_random_configs_fast_vs_generic(nfft):
             assert normwise(got_d, ref_d) <= tol, (trial, cfg, 'dense', normwise(got_d, ref_d))
     assert n_fast >= 15, n_fast
     print(f'nfft={nfft}: {n_fast} configurations on the fast path, worst normwise {worst:.2e}')
+
+
+@pytest.mark.parametrize('dtype', [np.int16, np.float64])
+def test_random_clips_endpoints_exact(dtype):
+    """300 random clips (length, burst count / position / level, noise floor) through the batched
+    device endpointing: every (left, right) pair must equal the oracle's (endpoint.py:34-66)."""
+    from features.batch import EndpointPlan
+    from oracle import dsp_oracle
+    rng = np.random.default_rng(77)
+    clips = []
+    for _ in range(300):
+        n = int(rng.uniform(0.2, 3.0) * 16000)
+        x = rng.normal(0, rng.choice([1.0, 30.0, 300.0]), n)
+        for _ in range(int(rng.integers(0, 4))):
+            blen = int(rng.uniform(0.05, 0.9) * n)
+            b0 = int(rng.integers(0, max(1, n - blen)))
+            t = np.arange(blen) / 16000.0
+            x[b0:b0 + blen] += rng.choice([200.0, 2000.0, 8000.0]) * np.sin(2 * np.pi * rng.uniform(80, 3000) * t) * np.hanning(blen)
+        x = np.clip(np.round(x), -32768, 32767)
+        clips.append(x.astype(np.int16) if dtype == np.int16 else x / 32768.0)
+    so = np.concatenate([[0], np.cumsum([len(c) for c in clips])]).astype(np.int64)
+    flat = np.concatenate(clips)
+    got = EndpointPlan(16000, 0.03, 0.01).detect_batch(flat.astype(np.float32) if dtype != np.int16 else flat,
+                                                       sample_offsets=so)
+    bad = []
+    for b, c in enumerate(clips):
+        ref_in = c if dtype == np.int16 else c.astype(np.float32)     # the device sees fp32 samples
+        if tuple(got[b]) != dsp_oracle.basic_endpoint_detection(ref_in, 16000):
+            bad.append((b, tuple(got[b]), dsp_oracle.basic_endpoint_detection(ref_in, 16000)))
+    assert not bad, bad[:5]
