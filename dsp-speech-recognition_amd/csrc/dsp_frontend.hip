@@ -446,6 +446,22 @@ int dsp_trim_scale_batch(const void* d_wave, int wave_dtype, const int64_t* d_sa
     return DSP_OK;
 }
 
+int dsp_model_finalize_batch(const float* d_mfcc, int64_t ld_in, const int64_t* d_frame_offsets, int32_t n_utt,
+                             int32_t C, int32_t N, int32_t max_len, float* d_out, int32_t* d_len0, void* stream) {
+    if (!d_mfcc || !d_frame_offsets || !d_out || !d_len0 || n_utt <= 0)
+        return fail(DSP_EINVAL, "dsp_model_finalize_batch: bad arguments");
+    if (N < 1) return fail(DSP_EINVAL, "N must be an integer >= 1");  // base.py:71-72
+    if (C <= 0 || C > 32 || max_len <= 0) return fail(DSP_EINVAL, "need 0 < C <= 32 and max_len > 0");
+    if (ld_in == 0) ld_in = C;
+    if (ld_in < C) return fail(DSP_EINVAL, "ld_in %lld < C %d", (long long)ld_in, C);
+    const size_t lds = ((size_t)(max_len + 2 * N) + (size_t)(max_len + N)) * C * sizeof(float);
+    if (lds > 64 * 1024) return fail(DSP_EINVAL, "max_len * C too large for the LDS tile (%zu bytes)", lds);
+    model_finalize_kernel<<<n_utt, 256, lds, (hipStream_t)stream>>>(d_mfcc, ld_in, d_frame_offsets, n_utt, C, N,
+                                                                   max_len, d_out, d_len0);
+    HIP_TRY(hipGetLastError());
+    return DSP_OK;
+}
+
 int dsp_endpoint_rule_batch(const double* d_amp_sum, const int32_t* d_zcr, const int64_t* d_frame_offsets,
                             int32_t n_utt, int32_t frame_len, double cfg_frame, double cfg_step,
                             int32_t* d_endpoints, void* stream) {

@@ -528,3 +528,93 @@ __global__ __launch_bounds__(256) void trim_scale_kernel(const void* __restrict_
     for (int64_t i = threadIdx.x; i < n; i += 256)
         dst[i] = (float)((double)dsp_load_sample<DTYPE>(wave, s0 + i) * inv);
 }
+
+// model.py:66-88 after the MFCC call, plus the 200-frame layout of model.py:35-50,131-135, one
+// workgroup per utterance:
+//   x  = mfcc0 - mean(mfcc0)               scalar mean over the whole [T, C] block   (model.py:75)
+//   d1 = delta(x, N), d2 = delta(d1, N)    edge replicated, base.py:70-79            (model.py:76-77)
+//   z  = (x - mean_c) / std_c              per coefficient, population std, 0 -> 1   (model.py:78)
+//   out[t, b, :] = z | d1 | d2 for t < min(T, max_len), zeros up to max_len          (model.py:35-50)
+// Statistics in fp64 over all T frames; only the first max_len (+ halo) rows are staged in LDS.
+__global__ __launch_bounds__(256) void model_finalize_kernel(const float* __restrict__ mfcc, int64_t ld_in,
+                                                             const int64_t* __restrict__ frame_off, int32_t n_utt,
+                                                             int32_t C, int32_t N, int32_t max_len,
+                                                             float* __restrict__ out, int32_t* __restrict__ len0) {
+    extern __shared__ __attribute__((aligned(16))) float fin_smem[];
+    __shared__ double red[4];
+    __shared__ double s_mu[32], s_inv[32];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int64_t base = frame_off[b];
+    const int T = (int)(frame_off[b + 1] - base);
+    const int keep = T < max_len ? T : max_len;
+    const float* in = mfcc + base * ld_in;
+    // scalar mean of the block
+    double s = 0.0;
+    for (int i = tid; i < T * C; i += 256) s += (double)in[(int64_t)(i / C) * ld_in + (i % C)];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    const double gmean = T > 0 ? (red[0] + red[1] + red[2] + red[3]) / ((double)T * (double)C) : 0.0;
+    __syncthreads();
+    // per-coefficient mean and population std of x = mfcc - gmean (two passes, like numpy)
+    const int wid = tid >> 6, lane = tid & 63;
+    for (int c = wid; c < C; c += 4) {
+        double a = 0.0;
+        for (int t = lane; t < T; t += 64) a += (double)(float)((double)in[(int64_t)t * ld_in + c] - gmean);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        const double mu = T > 0 ? a / (double)T : 0.0;
+        double v = 0.0;
+        for (int t = lane; t < T; t += 64) {
+            const double dlt = (double)(float)((double)in[(int64_t)t * ld_in + c] - gmean) - mu;
+            v += dlt * dlt;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) {
+            const double sd = T > 0 ? sqrt(v / (double)T) : 0.0;
+            s_mu[c] = mu;
+            s_inv[c] = sd == 0.0 ? 1.0 : 1.0 / sd;
+        }
+    }
+    // stage x rows [0, nx) and d1 rows [0, nd): what the first `keep` output rows can reach
+    const int nx = (keep + 2 * N < T) ? keep + 2 * N : T;
+    const int nd = (keep + N < T) ? keep + N : T;
+    float* sx = fin_smem;                       // [max_len + 2 N, C]
+    float* sd1 = fin_smem + (size_t)(max_len + 2 * N) * C;   // [max_len + N, C]
+    for (int i = tid; i < nx * C; i += 256)
+        sx[i] = (float)((double)in[(int64_t)(i / C) * ld_in + (i % C)] - gmean);
+    __syncthreads();
+    double den = 0.0;
+    for (int n = 1; n <= N; ++n) den += (double)n * n;
+    const float inv_den = (float)(1.0 / (2.0 * den));
+    auto xat = [&](int t, int c) { t = t < 0 ? 0 : (t >= T ? T - 1 : t); return sx[t * C + c]; };
+    for (int i = tid; i < nd * C; i += 256) {
+        const int t = i / C, c = i % C;
+        float acc = 0.f;
+        for (int n = 1; n <= N; ++n) acc = fmaf((float)n, xat(t + n, c) - xat(t - n, c), acc);
+        sd1[i] = acc * inv_den;
+    }
+    __syncthreads();
+    auto dat = [&](int t, int c) { t = t < 0 ? 0 : (t >= T ? T - 1 : t); return sd1[t * C + c]; };
+    const int64_t row = (int64_t)n_utt * 3 * C;
+    float* ob = out + (int64_t)b * 3 * C;
+    for (int i = tid; i < max_len * C; i += 256) {
+        const int t = i / C, c = i % C;
+        float z = 0.f, d1 = 0.f, d2 = 0.f;
+        if (t < keep) {
+            z = (float)(((double)sx[i] - s_mu[c]) * s_inv[c]);
+            d1 = sd1[i];
+            float acc = 0.f;
+            for (int n = 1; n <= N; ++n) acc = fmaf((float)n, dat(t + n, c) - dat(t - n, c), acc);
+            d2 = acc * inv_den;
+        }
+        float* o = ob + (int64_t)t * row;
+        o[c] = z;
+        o[C + c] = d1;
+        o[2 * C + c] = d2;
+    }
+    if (tid == 0) len0[b] = keep;
+}
+

@@ -68,6 +68,24 @@ def batch_to_rnn_input(features, frame_offsets, max_len=200):
     return inp, lens.cpu().numpy()
 
 
+def model_finalize(mfcc0, frame_offsets, delta_n=3, max_len=200):
+    """Host-array form of dsp_model_finalize_batch: ``mfcc0`` [sum T_b, C] (the raw MFCCs of a
+    batch) -> (inp [max_len, B, 3C] fp32, len0 [B]) as model.py:75-78 + 35-50 build them."""
+    from . import _native as nat
+    nat.require_device()
+    lib = nat.load()
+    m = np.ascontiguousarray(mfcc0, dtype=np.float32)
+    fo = np.ascontiguousarray(frame_offsets, dtype=np.int64)
+    B, C = len(fo) - 1, m.shape[1]
+    d_in = nat.device_array('fin_in', m)
+    d_fo = nat.device_array('fin_fo', fo)
+    d_out = nat.SCRATCH.get('fin_out', max_len * B * 3 * C * 4)
+    d_len = nat.SCRATCH.get('fin_len', B * 4)
+    nat.check(lib.dsp_model_finalize_batch(d_in.ptr, C, d_fo.ptr, B, C, int(delta_n), int(max_len), d_out.ptr,
+                                           d_len.ptr, None))
+    return d_out.download((max_len, B, 3 * C), np.float32), d_len.download((B,), np.int32)
+
+
 class ModelFeatureBatch:
     """Batched, device-resident form of RNNModel.get_batch_full (model.py:113-135, augment=False):
     endpointing -> trim -> unit variance -> MFCC on the (1, N) view (no pre-emphasis, sigproc.py:185)
@@ -82,33 +100,19 @@ class ModelFeatureBatch:
         self.delta_n, self.max_len = delta_n, max_len
 
     def run(self, waves, sample_offsets):
-        """-> (inp [max_len, B, 39] torch tensor on cuda:0, len0 [B], endpoints [B, 2])."""
+        """-> (inp [max_len, B, 39] torch tensor on cuda:0, len0 [B], endpoints [B, 2]).
+        Everything between the raw waveforms and ``inp`` runs in the library's kernels
+        (dsp_vad_features / endpoint_rule / trim_scale / features / model_finalize); torch only
+        owns the result tensor, so it can go straight into the classifier."""
         import torch
         from . import _native as nat
         lib = nat.load()
-        m0, fo, ends = self.pipe.run(waves, sample_offsets, delta_n=0)       # [sum T, 13] host fp32
+        (d_m0, flay), fo, ends = self.pipe.run(waves, sample_offsets, delta_n=0, download=False)
+        B, C = flay.n_utt, self.pipe.features.C
         dev = torch.device('cuda', 0)
-        x = torch.from_numpy(m0).to(dev)
-        fo_t = torch.as_tensor(fo, device=dev)
-        lens = fo_t[1:] - fo_t[:-1]
-        B, C = lens.numel(), x.shape[1]
-        seg = torch.repeat_interleave(torch.arange(B, device=dev), lens)
-        # mfcc0 -= mean over the whole [T, 13] block of the utterance (model.py:75), in fp64
-        tot = torch.zeros(B, dtype=torch.float64, device=dev).index_add_(0, seg, x.double().sum(1))
-        x = (x.double() - (tot / (lens * C).double())[seg, None]).float().contiguous()
-        out = torch.empty((x.shape[0], 3 * C), dtype=torch.float32, device=dev)
-        out[:, :C] = x
-        d_fo = fo_t.contiguous()
-        st = torch.cuda.current_stream(dev).cuda_stream
-        nat.check(lib.dsp_delta_batch(out.data_ptr(), 3 * C, d_fo.data_ptr(), B, x.shape[0], 0, C, self.delta_n,
-                                      out.data_ptr() + 4 * C, 3 * C, out.data_ptr() + 8 * C, 3 * C, st))
-        # per-coefficient z-score of the static part only, AFTER the deltas were taken (model.py:78)
-        s1 = torch.zeros((B, C), dtype=torch.float64, device=dev).index_add_(0, seg, x.double())
-        mu = s1 / lens[:, None].double()
-        dlt = x.double() - mu[seg]
-        var = torch.zeros((B, C), dtype=torch.float64, device=dev).index_add_(0, seg, dlt * dlt) / lens[:, None].double()
-        sd = var.sqrt()
-        sd = torch.where(sd == 0, torch.ones_like(sd), sd)
-        out[:, :C] = (dlt / sd[seg]).float()
-        inp, len0 = batch_to_rnn_input(out, fo, self.max_len)
-        return inp, len0, ends
+        inp = torch.empty((self.max_len, B, 3 * C), dtype=torch.float32, device=dev)
+        len0 = torch.empty(B, dtype=torch.int32, device=dev)
+        nat.check(lib.dsp_model_finalize_batch(d_m0.ptr, C, flay.p_frame, B, C, self.delta_n, self.max_len,
+                                               inp.data_ptr(), len0.data_ptr(), None))
+        nat.check(lib.dsp_stream_synchronize(None))     # d_m0 is library scratch: done before it is reused
+        return inp, len0.cpu().numpy(), ends

@@ -34,9 +34,11 @@ class VadMfccPipeline:
         self.endpoint = EndpointPlan(rate, frame, step)
         self.features = FeaturePlan(**mfcc_kwargs)
 
-    def run(self, waves, sample_offsets, delta_n=2):
+    def run(self, waves, sample_offsets, delta_n=2, download=True):
         """waves: 1-D host array (int16 or float) of concatenated utterances.
-        Returns (features [sum T_b, D] fp32, frame_offsets [B+1], endpoints [B, 2] in samples)."""
+        Returns (features [sum T_b, D] fp32, frame_offsets [B+1], endpoints [B, 2] in samples);
+        with ``download=False`` the features stay on the device and the first element is the
+        (DeviceBuffer, _BatchLayout) pair of the result instead."""
         nat.require_device()
         lib = nat.load()
         so = np.ascontiguousarray(sample_offsets, dtype=np.int64)
@@ -77,5 +79,7 @@ class VadMfccPipeline:
         D = fp.width(delta_n)
         d_out = nat.SCRATCH.get('batch_out', flay.total_frames * D * 4)
         fp.run_raw(d_trim.ptr, nat.WAVE_F32, flay, d_out.ptr, delta_n, None)
+        if not download:
+            return (d_out, flay), flay.frame_offsets, ends
         out = d_out.download((flay.total_frames, D), np.float32)
         return out, flay.frame_offsets, ends

@@ -181,6 +181,22 @@ int dsp_trim_scale_batch(const void* d_wave, int wave_dtype, const int64_t* d_sa
                          const int64_t* d_segments, const int64_t* d_dst_offsets, int32_t n_utt,
                          int32_t unit_variance, float* d_out, void* stream);
 
+/* ---- model.py glue behind the feature call ----------------------------- */
+/*
+ * What model.py:66-88 does to mfcc0 = mfcc(...) of every utterance, and the [200, B, 39] layout of
+ * model.py:35-50,131-135, in one launch:
+ *   x  = mfcc0 - mean(mfcc0)             scalar mean of the utterance's [T, C] block   model.py:75
+ *   d1 = delta(x, N); d2 = delta(d1, N)  base.delta, edge replicated                  model.py:76-77
+ *   z  = (x - mean_c) / std_c            per coefficient, population std, 0 -> 1       model.py:78
+ *   d_out[t, b, 0:C | C:2C | 2C:3C] = z | d1 | d2 for t < min(T_b, max_len), zero rows up to max_len
+ *   d_len0[b] = min(T_b, max_len)
+ * d_mfcc: [sum T_b, C] (row stride ld_in, 0 = dense); d_out: [max_len, n_utt, 3C] fp32.
+ * Statistics are accumulated in fp64.
+ */
+int dsp_model_finalize_batch(const float* d_mfcc, int64_t ld_in, const int64_t* d_frame_offsets,
+                             int32_t n_utt, int32_t C, int32_t N, int32_t max_len, float* d_out,
+                             int32_t* d_len0, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -122,3 +122,30 @@ def test_library_first_then_torch_shares_one_hip_runtime():
     ) % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'dsp-speech-recognition_amd')
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and 'one-runtime-ok' in r.stdout, r.stdout + r.stderr
+
+
+def test_model_finalize_kernel_vs_oracle_arithmetic():
+    """dsp_model_finalize_batch on random cepstra of awkward lengths (1 frame, fewer frames than the
+    delta window, exactly / more than 200, a constant column whose std is 0) against model.py:75-78
+    restated with the oracle's delta."""
+    from features.model_glue import model_finalize
+    from conftest import normwise
+    rng = np.random.default_rng(5)
+    lens = [1, 2, 3, 7, 150, 200, 201, 333, 64]
+    fo = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+    m = (rng.standard_normal((fo[-1], 13)) * rng.uniform(0.5, 20, 13) + rng.uniform(-30, 30, 13)).astype(np.float32)
+    m[fo[4]:fo[5], 5] = 3.25                                  # zero spread -> divide by 1 (sklearn)
+    inp, len0 = model_finalize(m, fo, delta_n=3, max_len=200)
+    assert inp.shape == (200, len(lens), 39)
+    for b, T in enumerate(lens):
+        x = m[fo[b]:fo[b + 1]].astype(np.float64)
+        x = (x - x.mean()).astype(np.float32).astype(np.float64)      # the kernel keeps x in fp32
+        d1 = dsp_oracle.delta(x, 3)
+        d2 = dsp_oracle.delta(d1, 3)
+        sd = x.std(axis=0)
+        z = (x - x.mean(axis=0)) / np.where(sd == 0, 1.0, sd)
+        n = min(T, 200)
+        assert len0[b] == n
+        ref = np.concatenate([z, d1, d2], axis=1)[:n]
+        assert np.max(np.abs(inp[:n, b] - ref)) <= 2e-5 * max(1.0, np.max(np.abs(ref))), (b, T)
+        assert not inp[n:, b].any()
