@@ -88,6 +88,88 @@ def cpu_baseline(budget_s=8.0):
     }
 
 
+def other_paths(dev):
+    """Short timings of the other kernels on the path (not part of `value`): the NFFT=1536 kernel
+    (48 kHz, 30 ms / 10 ms, 26 mel, 512 x 1 s) and the configs[3] stages on 1024
+    variable-length int16 utterances.  Reported for the record next to the headline number."""
+    import torch
+    from features import _native as nat
+    from features.batch import EndpointPlan, FeaturePlan, _BatchLayout
+    lib = nat.load()
+    st = torch.cuda.current_stream(dev).cuda_stream
+
+    def timed(fn, reps=30):
+        for _ in range(5):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / reps * 1e3          # us
+
+    out = {}
+    # --- NFFT = 1536 ---
+    b2, n2 = 512, 48000
+    p2 = FeaturePlan(samplerate=48000, winlen=0.03, winstep=0.01, numcep=13, nfilt=26, nfft=1536, preemph=0.97,
+                     ceplifter=22, appendEnergy=True, winfunc=np.hamming)
+    lay2 = p2.layout(np.empty((b2, n2), dtype=np.float32))
+    g = torch.Generator(device=dev).manual_seed(2)
+    w2 = 0.25 * torch.randn((b2, n2), device=dev, generator=g)
+    o2 = torch.empty((lay2.total_frames, 13), device=dev)
+    us = timed(lambda: p2.run_raw(w2.data_ptr(), nat.WAVE_F32, lay2, o2.data_ptr(), 0, st))
+    byt = 4.0 * b2 * n2 + 4.0 * lay2.total_frames * 13
+    out['nfft1536_mfcc'] = {'workload': '512 x 1 s at 48 kHz, 30 ms / 10 ms, nfft=1536, 26 mel -> 13 cep',
+                            'frames': lay2.total_frames, 'us_per_launch': us,
+                            'frames_per_s': lay2.total_frames / us * 1e6, 'algorithmic_GBps': byt / us / 1e3}
+    # --- configs[3]: VAD features -> endpoint rule -> trim + unit variance -> ragged MFCC+delta+delta2 ---
+    rng = np.random.default_rng(7)
+    sigs = []
+    for _ in range(B):
+        n = int(rng.uniform(1.0, 2.0) * 16000)
+        x = rng.normal(0, 30, n)
+        blen = int(rng.uniform(0.5, 0.9) * n)
+        b0 = int(rng.integers(0, n - blen))
+        t = np.arange(blen) / 16000.0
+        x[b0:b0 + blen] += 8000 * np.sin(2 * np.pi * rng.uniform(100, 300) * t) * np.hanning(blen)
+        sigs.append(np.clip(np.round(x), -32768, 32767).astype(np.int16))
+    so = np.concatenate([[0], np.cumsum([len(s_) for s_ in sigs])]).astype(np.int64)
+    d_wave = torch.from_numpy(np.concatenate(sigs)).to(dev)
+    ep = EndpointPlan(16000, 0.03, 0.01)
+    lay = _BatchLayout(ep.L, ep.S, B, sample_offsets=so)
+    nf = lay.total_frames
+    d_amp = torch.empty(nf, dtype=torch.float64, device=dev)
+    d_zcr = torch.empty(nf, dtype=torch.int32, device=dev)
+    d_ep = torch.empty((B, 2), dtype=torch.int32, device=dev)
+    t_vad = timed(lambda: nat.check(lib.dsp_vad_features_batch(
+        d_wave.data_ptr(), nat.WAVE_I16, lay.p_sample, lay.p_frame, B, nf, 0, ep.L, ep.S, 0, d_amp.data_ptr(),
+        d_zcr.data_ptr(), st)))
+    t_rule = timed(lambda: nat.check(lib.dsp_endpoint_rule_batch(
+        d_amp.data_ptr(), d_zcr.data_ptr(), lay.p_frame, B, ep.L, float(ep.frame), float(ep.step), d_ep.data_ptr(), st)))
+    fr = d_ep.cpu().numpy().astype(np.int64)
+    lens = np.diff(so)
+    ends = np.stack([np.minimum((fr[:, 0] * ep.step * ep.rate).astype(np.int64), lens),
+                     np.minimum((fr[:, 1] * ep.step * ep.rate).astype(np.int64), lens)], axis=1)
+    dst = np.concatenate([[0], np.cumsum(ends[:, 1] - ends[:, 0])]).astype(np.int64)
+    d_so, d_dst = torch.from_numpy(so).to(dev), torch.from_numpy(dst).to(dev)
+    d_seg = torch.from_numpy(np.ascontiguousarray(ends.reshape(-1))).to(dev)
+    d_trim = torch.empty(int(dst[-1]), dtype=torch.float32, device=dev)
+    t_trim = timed(lambda: nat.check(lib.dsp_trim_scale_batch(
+        d_wave.data_ptr(), nat.WAVE_I16, d_so.data_ptr(), d_seg.data_ptr(), d_dst.data_ptr(), B, 1, d_trim.data_ptr(), st)))
+    fp = FeaturePlan(winfunc=np.hamming, **CFG)
+    flay = _BatchLayout(fp.L, fp.S, B, sample_offsets=dst)
+    o3 = torch.empty((flay.total_frames, 39), device=dev)
+    t_mfcc = timed(lambda: fp.run_raw(d_trim.data_ptr(), nat.WAVE_F32, flay, o3.data_ptr(), DELTA_N, st))
+    out['configs3_vad_pipeline'] = {
+        'workload': f'{B} int16 utterances of 1-2 s at 16 kHz ({int(so[-1])} samples), burst in noise',
+        'vad_features_us': t_vad, 'endpoint_rule_us': t_rule, 'trim_scale_us': t_trim,
+        'ragged_mfcc_delta_us': t_mfcc, 'mfcc_frames': flay.total_frames,
+        'utterances_per_s': B / ((t_vad + t_rule + t_trim + t_mfcc) * 1e-6)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -97,6 +179,7 @@ def main():
     ap.add_argument('--streams', type=int, default=3, help='HIP streams the independent steps alternate over')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gather', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the NFFT=1536 / configs[3] side timings')
     args = ap.parse_args()
 
     import torch
@@ -248,6 +331,8 @@ def main():
     }
     if gather is not None:
         res['gather'] = gather
+    if rank == 0 and world == 1 and not args.no_extras:
+        res['other_paths'] = other_paths(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline()
     if rank == 0:
