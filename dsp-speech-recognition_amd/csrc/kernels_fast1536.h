@@ -618,9 +618,7 @@ static int fast1536_launch_t(F1536Params P, const void* d_wave, int dtype, const
     if (!w) return DSP_EHIP;
     int32_t* group_off = static_cast<int32_t*>(w->ptr);
     int32_t* group_utt = group_off + bg.n_utt + 1;
-    f512_group_prefix_kernel<<<1, 1024, 0, st>>>(bg.frame_off, bg.n_utt, 2, group_off);
-    const int fill_blocks = (int)((bg.n_utt + 255) / 256 < 1024 ? (bg.n_utt + 255) / 256 : 1024);
-    f512_group_fill_kernel<<<fill_blocks, 256, 0, st>>>(group_off, bg.n_utt, group_utt);
+    f512_build_group_tables(bg.frame_off, bg.n_utt, 2, group_off, group_utt, st);
     P.group_off = group_off;
     P.group_utt = group_utt;
     int rc;

@@ -489,7 +489,8 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
 // Ragged batches: group_off[b] = sum_{i<b} ceil(T_i / 2^shift) (exclusive prefix, single block), then the
 // utterance of every group.  Both are tiny next to the main kernel and run on the same stream.
 __global__ __launch_bounds__(1024) void f512_group_prefix_kernel(const int64_t* __restrict__ frame_off, int32_t n_utt,
-                                                                 int32_t shift, int32_t* __restrict__ group_off) {
+                                                                 int32_t shift, int32_t* __restrict__ group_off,
+                                                                 int32_t* __restrict__ group_utt = nullptr) {
     __shared__ int32_t part[1024];
     const int tid = threadIdx.x;
     const int per = (n_utt + 1023) / 1024;
@@ -508,15 +509,33 @@ __global__ __launch_bounds__(1024) void f512_group_prefix_kernel(const int64_t* 
     int32_t run = part[tid] - sum;
     for (int b = lo; b < hi; ++b) {
         group_off[b] = run;
-        run += (int32_t)((frame_off[b + 1] - frame_off[b] + rnd) >> shift);
+        const int32_t n = (int32_t)((frame_off[b + 1] - frame_off[b] + rnd) >> shift);
+        if (group_utt != nullptr)   // small batches: fill the group -> utterance table in the same launch
+            for (int32_t g = 0; g < n; ++g) group_utt[run + g] = b;
+        run += n;
     }
     if (tid == 1023) group_off[n_utt] = part[1023];
 }
+
+// Builds both ragged index tables on `st`: one launch for small batches, prefix + parallel fill otherwise.
+static inline void f512_build_group_tables(const int64_t* frame_off, int32_t n_utt, int32_t shift,
+                                           int32_t* group_off, int32_t* group_utt, hipStream_t st);
 
 __global__ __launch_bounds__(256) void f512_group_fill_kernel(const int32_t* __restrict__ group_off, int32_t n_utt,
                                                               int32_t* __restrict__ group_utt) {
     for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < n_utt; b += gridDim.x * blockDim.x)
         for (int g = group_off[b]; g < group_off[b + 1]; ++g) group_utt[g] = b;
+}
+
+static inline void f512_build_group_tables(const int64_t* frame_off, int32_t n_utt, int32_t shift,
+                                           int32_t* group_off, int32_t* group_utt, hipStream_t st) {
+    if (n_utt <= 4096) {
+        f512_group_prefix_kernel<<<1, 1024, 0, st>>>(frame_off, n_utt, shift, group_off, group_utt);
+        return;
+    }
+    f512_group_prefix_kernel<<<1, 1024, 0, st>>>(frame_off, n_utt, shift, group_off);
+    const int fill_blocks = (int)((n_utt + 255) / 256 < 1024 ? (n_utt + 255) / 256 : 1024);
+    f512_group_fill_kernel<<<fill_blocks, 256, 0, st>>>(group_off, n_utt, group_utt);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -690,9 +709,7 @@ static int fast512_launch_t(F512Params P, const void* d_wave, int dtype, const B
     if (!w) return DSP_EHIP;
     int32_t* group_off = static_cast<int32_t*>(w->ptr);
     int32_t* group_utt = group_off + bg.n_utt + 1;
-    f512_group_prefix_kernel<<<1, 1024, 0, st>>>(bg.frame_off, bg.n_utt, 3, group_off);
-    const int fill_blocks = (int)((bg.n_utt + 255) / 256 < 1024 ? (bg.n_utt + 255) / 256 : 1024);
-    f512_group_fill_kernel<<<fill_blocks, 256, 0, st>>>(group_off, bg.n_utt, group_utt);
+    f512_build_group_tables(bg.frame_off, bg.n_utt, 3, group_off, group_utt, st);
     P.group_off = group_off;
     P.group_utt = group_utt;
     int rc;
