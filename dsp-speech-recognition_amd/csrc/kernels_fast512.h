@@ -339,13 +339,14 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         FFTReg<16>::run(u0);
         FFTReg<16>::run(u1);
 
-        // power spectrum |X|^2 / 512 (rows carry a factor 2 -> 1/2048)
+        // power spectrum |X|^2 / 512: rows carry a factor 2 -> 1/2048.  That power of two is applied
+        // (exactly) to the mel weights at plan time and to the energy sum once, not to every bin.
         float p0[16], p1[16];
-        constexpr float S1 = 1.0f / 2048.0f, S2 = 1.0f / 32768.0f;
+        constexpr float S1 = 1.0f / 2048.0f, S2 = 1.0f / 16.0f;   // S2: the packed unit carries 8, not 2
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            p0[k] = S1 * fmaf(u0[k].x, u0[k].x, u0[k].y * u0[k].y);
-            p1[k] = S1 * fmaf(u1[k].x, u1[k].x, u1[k].y * u1[k].y);
+            p0[k] = fmaf(u0[k].x, u0[k].x, u0[k].y * u0[k].y);
+            p1[k] = fmaf(u1[k].x, u1[k].x, u1[k].y * u1[k].y);
         }
         // Slot layout of p0 (unit 0): p0[k] -> bin c + 32 k (k < 8), bin 512 - 32 k - c (k >= 8).
         // Lane 0 (c = 0) owns bins 16 j instead: the even ones (32 k) fit the same slots, bin 256 is
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         for (int m = 0; m < 8; ++m) podd[m] = 0.f;
         if (c == 0) {
             // u0 = FFT16 of r[2m] + i r[2m+1]; finish the 32-point real FFT R[j] = X[16 j], j = 0..16
-            // (factor 8 carried -> 1/32768)
+            // (factor 8 carried: 1/16 relative to the other units)
             float R[17];
             const float e0 = u0[0].x + u0[0].y, e16 = u0[0].x - u0[0].y;
             R[0] = S2 * 4.f * e0 * e0;
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
 #pragma unroll
             for (int k = 0; k < 16; ++k) energy += p1[k];
         }
-        energy = frame_allreduce(energy);
+        energy = S1 * frame_allreduce(energy);
         if (energy == 0.f) energy = DSP_EPS_F32;
 
         // ---- power spectrum -> LDS row of this frame: two base registers, immediate offsets ----
@@ -615,7 +616,7 @@ static inline int fast512_plan_init(dsp_plan* p, const dsp_plan_desc* d, const i
                     lead += shift;
                 }
                 for (int s2 = 0; s2 < d->h_mel_count[j]; ++s2)
-                    melw[(size_t)c * melw_row + pos + lead + s2] = d->h_mel_weights[mel_off[j] + s2];
+                    melw[(size_t)c * melw_row + pos + lead + s2] = d->h_mel_weights[mel_off[j] + s2] * (1.0f / 2048.0f);
             }
             memcpy(&mels[(size_t)i * 8 + c], &start, 4);
             pos += len;
