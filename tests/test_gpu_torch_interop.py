@@ -149,3 +149,34 @@ def test_model_finalize_kernel_vs_oracle_arithmetic():
         ref = np.concatenate([z, d1, d2], axis=1)[:n]
         assert np.max(np.abs(inp[:n, b] - ref)) <= 2e-5 * max(1.0, np.max(np.abs(ref))), (b, T)
         assert not inp[n:, b].any()
+
+
+def test_ragged_calls_on_three_streams_at_once():
+    """Ragged batches in flight on three HIP streams at the same time (each call leases its own
+    index-table workspace from the pool): results equal the same calls issued one by one."""
+    import torch
+    from features.batch import FeaturePlan
+    from features import _native as nat
+    dev = torch.device('cuda', 0)
+    plan = FeaturePlan(winfunc=np.hamming, **CFG)
+    rng = np.random.default_rng(33)
+    jobs = []
+    for j in range(9):
+        lens = rng.integers(1, 12000, int(rng.integers(5, 60)))
+        so = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+        flat = torch.from_numpy((0.25 * rng.standard_normal(so[-1])).astype(np.float32)).to(dev)
+        lay = plan.layout(flat, so)
+        alone = torch.empty((lay.total_frames, 39), device=dev)
+        plan.run_raw(flat.data_ptr(), nat.WAVE_F32, lay, alone.data_ptr(), 2, torch.cuda.current_stream(dev))
+        jobs.append((flat, lay, alone, torch.empty_like(alone)))
+    torch.cuda.synchronize(dev)
+    streams = [torch.cuda.Stream(dev) for _ in range(3)]
+    for rep in range(4):
+        for j, (flat, lay, alone, out) in enumerate(jobs):
+            out.zero_()
+        torch.cuda.synchronize(dev)
+        for j, (flat, lay, alone, out) in enumerate(jobs):
+            plan.run_raw(flat.data_ptr(), nat.WAVE_F32, lay, out.data_ptr(), 2, streams[j % 3])
+        torch.cuda.synchronize(dev)
+        for j, (flat, lay, alone, out) in enumerate(jobs):
+            assert torch.equal(out, alone), (rep, j)
