@@ -19,6 +19,7 @@ struct VadParams {
     int32_t L, S, use_sq;
     int32_t span_vec;       // ceil(((FR - 1) S + L) / 4)
     int32_t wave_floats;    // per-wave LDS region (floats)
+    int32_t off_a4, off_e;  // vad_vec_kernel: per-vector |x| sums / sign-change bits behind the samples
     int64_t groups_per_utt, total_groups;   // uniform batches
     const int32_t* group_off;               // ragged: [B+1] prefix of ceil(T_b / FR)
     const int32_t* group_utt;
@@ -142,6 +143,139 @@ __global__ __launch_bounds__(64 * VAD_WAVES) void vad_tile_kernel(VadParams P, B
     }
 }
 
+
+// int16 input, sum |x|: every sample is visited ONCE.  While a vector of four samples is being staged
+// its lane also forms a4 = |x0|+|x1|+|x2|+|x3| (exact in fp32) and four sign-change bits e_i for the
+// pairs (i-1, i); a frame is then the sum of the ~L/4 vector totals strictly inside it plus two edge
+// vectors resolved from the staged samples and a bit mask.  Same results as the walk above, ~3.5x
+// fewer instructions.
+template <int FR, bool RAGGED>
+__global__ __launch_bounds__(64 * VAD_WAVES) void vad_vec_kernel(VadParams P, BatchGeom bg,
+                                                                 const void* __restrict__ wave,
+                                                                 double* __restrict__ amp_sum,
+                                                                 int32_t* __restrict__ zcr) {
+    constexpr int LPF = 64 / FR;
+    constexpr int SHIFT = FR == 16 ? 4 : (FR == 8 ? 3 : 2);
+    extern __shared__ __attribute__((aligned(256))) float smem_f[];
+    const int tid = threadIdx.x;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    float* xs = smem_f + wid * P.wave_floats;
+    float* a4s = xs + P.off_a4;
+    int32_t* es = reinterpret_cast<int32_t*>(xs + P.off_e);
+    const int total_groups = RAGGED ? P.group_off[bg.n_utt] : (int)P.total_groups;
+    const int gstride = (int)gridDim.x * VAD_WAVES;
+    const int f = lane / LPF, q = lane % LPF;
+    const int L = P.L, S = P.S;
+
+    for (int G = __builtin_amdgcn_readfirstlane((int)blockIdx.x * VAD_WAVES + wid); G < total_groups; G += gstride) {
+        int utt, t0, T, nsamp;
+        int64_t s0, row0;
+        if constexpr (RAGGED) {
+            utt = P.group_utt[G];
+            t0 = (G - P.group_off[utt]) << SHIFT;
+            s0 = bg.sample_off[utt];
+            nsamp = (int)(bg.sample_off[utt + 1] - s0);
+            row0 = bg.frame_off[utt];
+            T = (int)(bg.frame_off[utt + 1] - row0);
+        } else {
+            const int gpu = (int)P.groups_per_utt;
+            utt = G / gpu;
+            t0 = (G - utt * gpu) << SHIFT;
+            nsamp = (int)bg.uniform_samples;
+            T = (int)bg.uniform_frames;
+            s0 = (int64_t)utt * bg.uniform_samples;
+            row0 = (int64_t)utt * bg.uniform_frames;
+        }
+        const int base = t0 * S;
+        const int64_t g0 = s0 + base;
+        const int d = RAGGED ? (int)(g0 & 3) : 0;
+        {
+            const int64_t a0 = g0 - d;
+            const int span_vec = RAGGED ? P.span_vec + 1 : P.span_vec;
+            F512Raw<DSP_WAVE_I16> raw[VAD_NSTAGE];
+#pragma unroll
+            for (int r = 0; r < VAD_NSTAGE; ++r) {
+                const int v = lane + 64 * r;
+                const int rel = base - d + 4 * v;
+                const bool touch = v < span_vec && rel + 3 >= 0 && rel < nsamp;
+                raw[r] = f512_load_raw<DSP_WAVE_I16>(wave, touch ? a0 + 4 * v : 0);
+            }
+            float left = 0.f;   // the pair (first staged sample - 1, first staged sample) is never inside a frame
+#pragma unroll
+            for (int r = 0; r < VAD_NSTAGE; ++r) {
+                const int v = lane + 64 * r;
+                const int rel = base - d + 4 * v;
+                float x[4];
+                f512_unpack<DSP_WAVE_I16>(raw[r], x);
+                float4 y = make_float4(x[0], x[1], x[2], x[3]);
+                if (rel + 0 < 0 || rel + 0 >= nsamp) y.x = 0.f;   // zero padding (sigproc.py:84-87)
+                if (rel + 1 < 0 || rel + 1 >= nsamp) y.y = 0.f;
+                if (rel + 2 < 0 || rel + 2 >= nsamp) y.z = 0.f;
+                if (rel + 3 < 0 || rel + 3 >= nsamp) y.w = 0.f;
+                const float prev = f512_shift_in(y.w, left);
+                left = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y.w), 63));
+                // int16 products cannot underflow: x[i-1] * x[i] < 0 is the exact sign-pair test
+                const uint32_t b0 = prev * y.x < 0.f, b1 = y.x * y.y < 0.f, b2 = y.y * y.z < 0.f, b3 = y.z * y.w < 0.f;
+                const uint32_t bits = b0 | (b1 << 1) | (b2 << 2) | (b3 << 3);
+                if (v < span_vec) {
+                    *reinterpret_cast<float4*>(xs + 4 * v) = y;
+                    a4s[v] = (fabsf(y.x) + fabsf(y.y)) + (fabsf(y.z) + fabsf(y.w));
+                    es[v] = (int32_t)(bits | ((b0 + b1 + b2 + b3) << 8));
+                }
+            }
+        }
+        F512_FENCE();
+
+        // frame f = samples [s, e) of the LDS image; vectors vL and vR hold its two ends
+        const int s = d + f * S, e = s + L;
+        const int vL = s >> 2, vR = e >> 2;
+        float accf = 0.f;
+        int32_t cnt = 0;
+        for (int v0 = vL + 1 + q; v0 < vR; v0 += 8 * LPF) {
+            float av[8];
+            int32_t ev[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int v = min(v0 + u * LPF, vR - 1);
+                av[u] = a4s[v];
+                ev[u] = es[v];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool in = v0 + u * LPF < vR;
+                accf += in ? av[u] : 0.f;
+                cnt += in ? (ev[u] >> 8) : 0;
+            }
+        }
+        if (q == 0) {
+            // left edge: offsets k..3 of vector vL, pairs (i-1, i) only for i >= s + 1
+            const int k = s & 3;
+            const float4 xl = *reinterpret_cast<const float4*>(xs + 4 * vL);
+            accf += (k <= 0 ? fabsf(xl.x) : 0.f) + (k <= 1 ? fabsf(xl.y) : 0.f) + (k <= 2 ? fabsf(xl.z) : 0.f) + fabsf(xl.w);
+            cnt += __builtin_popcount((uint32_t)es[vL] & (0xFu << (k + 1)) & 0xFu);
+            // right edge: offsets 0..m-1 of vector vR (absent when the frame ends on a vector boundary)
+            const int m = e & 3;
+            const float4 xr = *reinterpret_cast<const float4*>(xs + 4 * vR);
+            accf += (m > 0 ? fabsf(xr.x) : 0.f) + (m > 1 ? fabsf(xr.y) : 0.f) + (m > 2 ? fabsf(xr.z) : 0.f);
+            cnt += __builtin_popcount((uint32_t)es[vR] & ((1u << m) - 1u));
+        }
+        double acc = (double)accf;    // lane partials are exact integers below 2^24
+#pragma unroll
+        for (int o = LPF / 2; o > 0; o >>= 1) {
+            acc += __shfl_xor(acc, o, 64);
+            cnt += __shfl_xor(cnt, o, 64);
+        }
+        const int t = t0 + f;
+        if (q == 0 && t < T) {
+            amp_sum[row0 + t] = acc;
+            zcr[row0 + t] = cnt;
+        }
+        F512_FENCE();
+    }
+}
+
 // Picks the tile shape; returns 0 if the configuration has to take the one-wave-per-frame kernel.
 static inline int vad_tile_frames(int32_t L, int32_t S) {
     if (L < 64 || S < 1) return 0;
@@ -173,6 +307,29 @@ static int vad_tile_launch_k(const VadParams& P, const BatchGeom& bg, const void
     }
     // int16 samples: the |x| sum of one lane stays below 2^24, so fp32 partial sums are exact
     const bool f32_exact = DTYPE == DSP_WAVE_I16 && !P.use_sq && (P.L + 64 / FR - 1) / (64 / FR) < 512;
+    if (f32_exact && !getenv("DSP_VAD_WALK")) {
+        // visit-once kernel: samples + per-vector sums + sign bits per wave (6 floats per staged vector)
+        VadParams Q = P;
+        Q.off_a4 = 4 * (P.span_vec + 1);
+        Q.off_e = 5 * (P.span_vec + 1);
+        Q.wave_floats = (6 * (P.span_vec + 1) + 63) / 64 * 64;
+        const size_t lds2 = (size_t)VAD_WAVES * Q.wave_floats * sizeof(float);
+        auto k = vad_vec_kernel<FR, RAGGED>;
+        static size_t lds_set = 0;
+        if (lds2 > 48 * 1024 && lds2 > lds_set) {
+            if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
+                return DSP_EHIP;
+            lds_set = lds2;
+        }
+        int64_t blocks2 = (groups_bound + VAD_WAVES - 1) / VAD_WAVES;
+        const int64_t cap2 = 256 * 2;
+        if (blocks2 > cap2) {
+            const int64_t rounds = (blocks2 + cap2 - 1) / cap2;
+            blocks2 = (blocks2 + rounds - 1) / rounds;
+        }
+        k<<<(int)blocks2, 64 * VAD_WAVES, lds2, st>>>(Q, bg, d_wave, d_amp, d_zcr);
+        return hipGetLastError() == hipSuccess ? DSP_OK : DSP_EHIP;
+    }
     if (f32_exact)
         vad_tile_kernel<DTYPE, FR, RAGGED, 0><<<(int)blocks, 64 * VAD_WAVES, lds, st>>>(P, bg, d_wave, d_amp, d_zcr);
     else if (!P.use_sq)
