@@ -430,15 +430,11 @@ __device__ __forceinline__ void amplitude_rule_dev(AmpT amp, int64_t T, double i
     if (!any) { left = 0; right = T; }
 }
 
-template <typename AmpT, typename ZcrT, typename SilT>
-__device__ __forceinline__ void endpoint_rule_body(AmpT amp, ZcrT z, SilT sil, int64_t T, double inv_L,
-                                                   double cfg_frame, double cfg_step, int32_t* __restrict__ out2) {
-    const int n_sil = (int)(0.100 / cfg_step);              // int(l_sil / cfg.step), endpoint.py:151
-    int64_t left = 0, right = T;
-    amplitude_rule_dev(amp, T, inv_L, 0.25, 0.100, n_sil, n_sil, 3.0, cfg_frame, sil, left, right);
-    if (right - left < 50)                                  // endpoint.py:44-45
-        amplitude_rule_dev(amp, T, inv_L, 0.125, 0.100, n_sil, n_sil, 3.0, cfg_frame, sil, left, right);
-    // zcr_rule, endpoint.py:201-220 (l_sil = 0 -> front slice empty; r_sil = 0.1)
+// endpoint.zcr_rule (endpoint.py:201-220; l_sil = 0 -> front slice empty, r_sil = 0.1) and the
+// <50-frame fallback of endpoint.py:60-62.
+template <typename ZcrT>
+__device__ __forceinline__ void endpoint_zcr_rule(ZcrT z, int64_t T, int64_t left, int64_t right, int n_sil,
+                                                  double cfg_frame, int32_t* __restrict__ out2) {
     const double max_shift = 0.400 / cfg_frame;
     const int64_t cr = (n_sil == 0 || n_sil > T) ? T : n_sil;
     double mu = 0.0, var = 0.0;
@@ -455,6 +451,17 @@ __device__ __forceinline__ void endpoint_rule_body(AmpT amp, ZcrT z, SilT sil, i
     out2[1] = (int32_t)k;
 }
 
+template <typename AmpT, typename ZcrT, typename SilT>
+__device__ __forceinline__ void endpoint_rule_body(AmpT amp, ZcrT z, SilT sil, int64_t T, double inv_L,
+                                                   double cfg_frame, double cfg_step, int32_t* __restrict__ out2) {
+    const int n_sil = (int)(0.100 / cfg_step);              // int(l_sil / cfg.step), endpoint.py:151
+    int64_t left = 0, right = T;
+    amplitude_rule_dev(amp, T, inv_L, 0.25, 0.100, n_sil, n_sil, 3.0, cfg_frame, sil, left, right);
+    if (right - left < 50)                                  // endpoint.py:44-45
+        amplitude_rule_dev(amp, T, inv_L, 0.125, 0.100, n_sil, n_sil, 3.0, cfg_frame, sil, left, right);
+    endpoint_zcr_rule(z, T, left, right, n_sil, cfg_frame, out2);
+}
+
 #define DSP_RULE_LDS_FRAMES 2048   // utterances up to this many frames are scanned out of LDS
 
 // One wavefront per utterance: the wave copies the utterance's amp / zcr rows into LDS (coalesced),
@@ -468,6 +475,9 @@ __global__ __launch_bounds__(64) void endpoint_rule_kernel(const double* __restr
     __shared__ double s_amp[DSP_RULE_LDS_FRAMES];
     __shared__ int32_t s_zcr[DSP_RULE_LDS_FRAMES];
     __shared__ double s_sil[DSP_MAX_SIL];
+    __shared__ double s_sorted[DSP_MAX_SIL];
+    __shared__ double s_thr[3];
+    __shared__ uint8_t s_cls[DSP_RULE_LDS_FRAMES];
     const int32_t b = blockIdx.x;
     if (b >= n_utt) return;
     const int64_t base = frame_off[b];
@@ -476,14 +486,91 @@ __global__ __launch_bounds__(64) void endpoint_rule_kernel(const double* __restr
     const int32_t* z = zcr + base;
     const double inv_L = 1.0 / (double)L;
     if (T <= DSP_RULE_LDS_FRAMES) {
-        for (int i = threadIdx.x; i < (int)T; i += 64) {
-            s_amp[i] = amp[i] * inv_L;   // the per-frame mean, scaled once instead of at every use
+        // (1) whole wave: copy the rows, running maximum
+        const int lane = threadIdx.x;
+        double mx = amp[0] * inv_L;
+        for (int i = lane; i < (int)T; i += 64) {
+            const double v = amp[i] * inv_L;   // the per-frame mean, scaled once instead of at every use
+            s_amp[i] = v;
             s_zcr[i] = z[i];
+            mx = v > mx ? v : mx;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double other = __shfl_xor(mx, o, 64);
+            mx = other > mx ? other : mx;
         }
         __syncthreads();
-        if (threadIdx.x != 0) return;
-        // arrays passed by name: the scans compile to ds_read, not flat loads
-        endpoint_rule_body(s_amp, s_zcr, s_sil, T, 1.0, cfg_frame, cfg_step, endpoints + 2 * b);
+        // (2) silence window amp[:n] + amp[-n:] (endpoint.py:151-153), rank sort (stable: equal keys keep order)
+        const int n_sil = (int)(0.100 / cfg_step);
+        const int cl = n_sil < (int)T ? n_sil : (int)T;
+        const int cr = (n_sil == 0 || n_sil > (int)T) ? (int)T : n_sil;
+        const int ns = cl + cr;
+        for (int k = lane; k < ns; k += 64) s_sil[k] = k < cl ? s_amp[k] : s_amp[(int)T - cr + (k - cl)];
+        __syncthreads();
+        for (int k = lane; k < ns; k += 64) {
+            const double v = s_sil[k];
+            int rank = 0;
+            for (int j = 0; j < ns; ++j) {
+                const double w = s_sil[j];
+                rank += (w < v || (w == v && j < k)) ? 1 : 0;
+            }
+            s_sorted[rank] = v;
+        }
+        __syncthreads();
+        // (3) lane 0: statistics of sorted(sil)[:-2] in the reference's order, the two thresholds
+        if (lane == 0) {
+            const int m = ns - 2 > 0 ? ns - 2 : 0;
+            double mean = 0.0, var = 0.0;
+            for (int i = 0; i < m; ++i) mean += s_sorted[i];
+            mean = m > 0 ? mean / m : __longlong_as_double(0x7ff8000000000000LL);
+            for (int i = 0; i < m; ++i) var += (s_sorted[i] - mean) * (s_sorted[i] - mean);
+            const double sd = m > 0 ? sqrt(var / m) : mean;
+            const double M_L = mean + 3.0 * sd;
+            const double a1 = mx * 0.25, a2 = mx * 0.125;            // mh, and the retry of endpoint.py:44-45
+            s_thr[0] = M_L;
+            s_thr[1] = (M_L > a1) ? M_L : a1;                         // python max(a, M_L): NaN M_L loses
+            s_thr[2] = (M_L > a2) ? M_L : a2;
+        }
+        __syncthreads();
+        // (4) whole wave: every comparison the scans can ask for, one byte per frame
+        {
+            const double M_L = s_thr[0], M_H1 = s_thr[1], M_H2 = s_thr[2];
+            for (int i = lane; i < (int)T; i += 64) {
+                const double v = s_amp[i];
+                s_cls[i] = (uint8_t)((v > M_L ? 1 : 0) | (v > M_H1 ? 2 : 0) | (v >= M_H1 ? 4 : 0) |
+                                     (v > M_H2 ? 8 : 0) | (v >= M_H2 ? 16 : 0));
+            }
+        }
+        __syncthreads();
+        if (lane != 0) return;
+        // (5) lane 0: the two-threshold scan (endpoint.py:155-179) on the class bytes
+        const double T_H = 0.100 / cfg_frame;
+        int64_t left = 0, right = T;
+        for (int pass = 0; pass < 2; ++pass) {
+            const uint8_t hi = pass == 0 ? 2 : 8, ge = pass == 0 ? 4 : 16;
+            bool any = false;
+            int64_t i = 0;
+            while (i < T) {
+                if (s_cls[i] & ge) {
+                    int64_t j = i, k = i;
+                    while (k < T && (s_cls[k] & hi)) ++k;
+                    if ((double)(k - j) < T_H) {
+                        i = k;
+                    } else {
+                        while (j > 0 && (s_cls[j] & 1)) --j;
+                        while (k < T && (s_cls[k] & 1)) ++k;
+                        if (!any) { left = j; any = true; }
+                        right = k;
+                        i = k;
+                    }
+                }
+                ++i;
+            }
+            if (!any) { left = 0; right = T; }
+            if (right - left >= 50) break;                             // endpoint.py:44-45
+        }
+        endpoint_zcr_rule(s_zcr, T, left, right, n_sil, cfg_frame, endpoints + 2 * b);
     } else {
         if (threadIdx.x != 0) return;
         endpoint_rule_body(amp, z, s_sil, T, inv_L, cfg_frame, cfg_step, endpoints + 2 * b);
