@@ -592,7 +592,19 @@ __global__ __launch_bounds__(256) void trim_scale_kernel(const void* __restrict_
     double inv = 1.0;
     if (unit_variance && n > 0) {
         double s = 0.0, q = 0.0;
-        for (int64_t i = threadIdx.x; i < n; i += 256) {
+        // eight independent loads in flight per thread (the loop is latency bound otherwise)
+        int64_t i = threadIdx.x;
+        for (; i + 7 * 256 < n; i += 8 * 256) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = dsp_load_sample<DTYPE>(wave, s0 + i + u * 256);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s += (double)v[u];
+                q += (double)v[u] * (double)v[u];
+            }
+        }
+        for (; i < n; i += 256) {
             const double v = (double)dsp_load_sample<DTYPE>(wave, s0 + i);
             s += v;
             q += v * v;
@@ -612,7 +624,15 @@ __global__ __launch_bounds__(256) void trim_scale_kernel(const void* __restrict_
         const double sd = sqrt(var);
         inv = sd > 0.0 ? 1.0 / sd : 1.0;
     }
-    for (int64_t i = threadIdx.x; i < n; i += 256)
+    int64_t i = threadIdx.x;
+    for (; i + 7 * 256 < n; i += 8 * 256) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = dsp_load_sample<DTYPE>(wave, s0 + i + u * 256);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dst[i + u * 256] = (float)((double)v[u] * inv);
+    }
+    for (; i < n; i += 256)
         dst[i] = (float)((double)dsp_load_sample<DTYPE>(wave, s0 + i) * inv);
 }
 
