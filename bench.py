@@ -322,6 +322,7 @@ def main():
                    'sharding': f'{world} ranks x independent batches, no data-path collective'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
+                     'frac_of_measured_copy_ceiling': achieved / 6290.0,   # MI355X_MICROARCH.md: 6.29 TB/s copy
                      'algorithmic_bytes_per_launch': BYTES_PER_FRAME_MFCC * B * T,
                      'kernel': 'fused MFCC kernel (dsp_features_batch, DSP_OUT_MFCC)',
                      'kernel_ms': kernel_ms, 'bytes_per_frame': BYTES_PER_FRAME_MFCC,
