@@ -13,7 +13,8 @@
  *   - every function returns DSP_OK (0) or a negative DSP_E* code; dsp_last_error() gives the
  *     thread-local message.  Nothing falls back to a CPU path: without a GPU calls fail.
  *   - waveform buffers must start 16-byte aligned (hipMalloc / torch allocations are) for the
- *     specialised kernel to be used; unaligned buffers silently take the generic kernel.
+ *     specialised kernels to be used; unaligned buffers silently take the generic kernels (same
+ *     results, slower).
  *   - utterances are concatenated: sample_offsets[B+1] (int64) into the wave buffer,
  *     frame_offsets[B+1] (int64) into the [sum T_b, D] output (row-major, fp32).
  *   - no global mutable state besides the thread-local error string; a plan is immutable after
@@ -95,7 +96,7 @@ int dsp_frame_offsets(const int64_t* h_sample_offsets, int32_t n_utt, int32_t fr
 /* ---- plans --------------------------------------------------------------------------------- */
 int dsp_plan_create(const dsp_plan_desc* desc, dsp_plan** plan);
 int dsp_plan_destroy(dsp_plan* plan);
-/* 1 if the plan is served by the specialised NFFT=512 kernel, 0 if only by the generic one */
+/* 1 if the plan is served by a specialised fused kernel (NFFT = 512 or 1536), 0 if only by the generic one */
 int dsp_plan_has_fast_path(const dsp_plan* plan);
 /* testing aid: route DSP_OUT_MFCC through the generic kernel even when the fast one applies
    (process-wide flag; the two kernels are independent implementations and must agree) */
