@@ -592,12 +592,8 @@ static int fast1536_launch_k(const F1536Params& P, const void* d_wave, const Bat
         blocks = (blocks + rounds - 1) / rounds;
     }
     auto k = mfcc1536_kernel<NI, NC, NSTAGE, DTYPE, F1536_WAVES, RAGGED>;
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return DSP_EHIP;
-        lds_set = lds;
-    }
+    static size_t granted[DSP_MAX_DEVICES] = {};
+    if (dsp_ensure_dynamic_lds((const void*)k, lds, granted) != 0) return DSP_EHIP;
     k<<<(int)blocks, 64 * F1536_WAVES, lds, st>>>(P, bg, d_wave, d_out, ld_out);
     return hipGetLastError() == hipSuccess ? DSP_OK : DSP_EHIP;
 }

@@ -683,12 +683,8 @@ static int fast512_launch_k(const F512Params& P, const void* d_wave, const Batch
         blocks = (blocks + rounds - 1) / rounds;
     }
     auto k = mfcc512_kernel<NROWS, NI, NC, NSTAGE, DTYPE, F512_WAVES, RAGGED>;
-    static size_t lds_set = 0;  // raise the dynamic-LDS limit once per instantiation (and on growth)
-    if (lds > lds_set) {
-        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return DSP_EHIP;
-        lds_set = lds;
-    }
+    static size_t granted[DSP_MAX_DEVICES] = {};  // dynamic-LDS limit already raised, per device
+    if (dsp_ensure_dynamic_lds((const void*)k, lds, granted) != 0) return DSP_EHIP;
     k<<<(int)blocks, 64 * F512_WAVES, lds, st>>>(P, bg, d_wave, d_out, ld_out);
     return hipGetLastError() == hipSuccess ? DSP_OK : DSP_EHIP;
 }

@@ -307,7 +307,8 @@ static int vad_tile_launch_k(const VadParams& P, const BatchGeom& bg, const void
     }
     // int16 samples: the |x| sum of one lane stays below 2^24, so fp32 partial sums are exact
     const bool f32_exact = DTYPE == DSP_WAVE_I16 && !P.use_sq && (P.L + 64 / FR - 1) / (64 / FR) < 512;
-    if (f32_exact && !getenv("DSP_VAD_WALK")) {
+    static const bool force_walk = getenv("DSP_VAD_WALK") != nullptr;   // A/B aid: keep the per-frame walk
+    if (f32_exact && !force_walk) {
         // visit-once kernel: samples + per-vector sums + sign bits per wave (6 floats per staged vector)
         VadParams Q = P;
         Q.off_a4 = 4 * (P.span_vec + 1);
@@ -315,12 +316,8 @@ static int vad_tile_launch_k(const VadParams& P, const BatchGeom& bg, const void
         Q.wave_floats = (6 * (P.span_vec + 1) + 63) / 64 * 64;
         const size_t lds2 = (size_t)VAD_WAVES * Q.wave_floats * sizeof(float);
         auto k = vad_vec_kernel<FR, RAGGED>;
-        static size_t lds_set = 0;
-        if (lds2 > 48 * 1024 && lds2 > lds_set) {
-            if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
-                return DSP_EHIP;
-            lds_set = lds2;
-        }
+        static size_t granted[DSP_MAX_DEVICES] = {};
+        if (lds2 > 48 * 1024 && dsp_ensure_dynamic_lds((const void*)k, lds2, granted) != 0) return DSP_EHIP;
         int64_t blocks2 = (groups_bound + VAD_WAVES - 1) / VAD_WAVES;
         const int64_t cap2 = 256 * 2;
         if (blocks2 > cap2) {

@@ -75,3 +75,17 @@ inline DspWorkspacePool& dsp_workspace_pool() {
     static DspWorkspacePool* pool = new DspWorkspacePool();  // never destroyed: no teardown-order issues with HIP
     return *pool;
 }
+
+// Raises a kernel's dynamic-LDS limit when needed.  The attribute is per device, so the largest
+// size already granted is remembered per device (`granted` is one static array per kernel
+// instantiation); concurrent callers may both set it, which is harmless.
+#define DSP_MAX_DEVICES 64
+inline int dsp_ensure_dynamic_lds(const void* kernel, size_t bytes, size_t (&granted)[DSP_MAX_DEVICES]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DSP_MAX_DEVICES) return -1;
+    if (bytes <= granted[dev]) return 0;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -1;
+    granted[dev] = bytes;
+    return 0;
+}
+
