@@ -295,6 +295,12 @@ int dsp_features_batch(const dsp_plan* plan, const void* d_wave, int wave_dtype,
                        int64_t n_frames_total, int64_t uniform_samples, int out_kind, float* d_out,
                        int64_t ld_out, float* d_out2, void* stream) {
     if (!plan || !d_out) return fail(DSP_EINVAL, "plan/d_out is NULL");
+    {
+        int dev = -1;
+        HIP_TRY(hipGetDevice(&dev));
+        if (dev != plan->device)   // the plan's tables live on the device it was created on
+            return fail(DSP_EINVAL, "plan belongs to device %d, current device is %d", plan->device, dev);
+    }
     int rc = check_geom(d_wave, wave_dtype, d_sample_offsets, d_frame_offsets, n_utt, n_frames_total, uniform_samples);
     if (rc != DSP_OK) return rc;
     int width;
