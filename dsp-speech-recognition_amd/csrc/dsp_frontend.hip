@@ -133,6 +133,12 @@ int dsp_set_device(int device) {
     return DSP_OK;
 }
 
+int dsp_get_device(int* device) {
+    if (!device) return fail(DSP_EINVAL, "dsp_get_device: NULL argument");
+    HIP_TRY(hipGetDevice(device));
+    return DSP_OK;
+}
+
 int dsp_malloc(void** d_ptr, size_t bytes) {
     if (!d_ptr) return fail(DSP_EINVAL, "d_ptr is NULL");
     HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 1));

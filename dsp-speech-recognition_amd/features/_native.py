@@ -37,6 +37,7 @@ SIGNATURES = {
     'dsp_last_error': (C.c_char_p, []),
     'dsp_device_count': (C.c_int, [C.POINTER(C.c_int)]),
     'dsp_set_device': (C.c_int, [C.c_int]),
+    'dsp_get_device': (C.c_int, [c_vp]),
     'dsp_malloc': (C.c_int, [C.POINTER(c_vp), C.c_size_t]),
     'dsp_free': (C.c_int, [c_vp]),
     'dsp_memcpy_h2d': (C.c_int, [c_vp, c_vp, C.c_size_t, c_vp]),
@@ -124,6 +125,13 @@ def load():
     return _lib
 
 
+def current_device():
+    """HIP device current on this thread (plans and scratch buffers are per device)."""
+    dev = C.c_int(-1)
+    check(load().dsp_get_device(C.byref(dev)))
+    return dev.value
+
+
 def check(rc):
     if rc != OK:
         msg = load().dsp_last_error()
@@ -204,6 +212,7 @@ class Scratch:
         self._lock = threading.Lock()
 
     def get(self, name, nbytes):
+        name = (current_device(), name)          # hipMalloc'ed memory belongs to one device
         with self._lock:
             b = self._bufs.get(name)
             if b is None or b.nbytes < nbytes:

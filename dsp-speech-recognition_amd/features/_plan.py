@@ -149,6 +149,7 @@ _CACHE_MAX = 64
 
 
 def _cached(key, build):
+    key = (nat.current_device(),) + tuple(key)      # a plan's tables live on the device it was built on
     with _cache_lock:
         p = _cache.get(key)
         if p is None:

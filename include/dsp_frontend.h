@@ -79,6 +79,7 @@ int         dsp_abi_version(void);
 const char* dsp_last_error(void);
 int dsp_device_count(int* n);
 int dsp_set_device(int device);
+int dsp_get_device(int* device);   /* plans, buffers and workspaces belong to the device current at creation */
 int dsp_malloc(void** d_ptr, size_t bytes);
 int dsp_free(void* d_ptr);
 int dsp_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream);
