@@ -183,10 +183,8 @@ class EndpointPlan:
             d_wave = nat.device_array('batch_wave', wave)
             self.run_raw(d_wave.ptr, dtype, layout, d_amp.ptr, d_zcr.ptr, d_ep.ptr, None)
         frames = d_ep.download((B, 2), np.int32)
-        samples = np.empty((B, 2), dtype=np.int64)
-        for b in range(B):  # fp64 product order of endpoint.py:64: (idx * step) * rate, then int()
-            samples[b, 0] = int(int(frames[b, 0]) * self.step * self.rate)
-            samples[b, 1] = int(int(frames[b, 1]) * self.step * self.rate)
+        # fp64 product order of endpoint.py:64: (idx * step) * rate, then int() -- vectorised
+        samples = ((frames.astype(np.float64) * self.step) * self.rate).astype(np.int64)
         if return_feature:
             amp = d_amp.download((nf,), np.float64) / self.L
             zcr = d_zcr.download((nf,), np.int32)
