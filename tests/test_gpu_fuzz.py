@@ -8,6 +8,7 @@ import pytest
 from conftest import normwise
 
 pytestmark = pytest.mark.gpu
+TOLD = 1e-4
 
 
 def _random_cfg(rng, nfft):
@@ -101,3 +102,41 @@ def test_random_clips_endpoints_exact(dtype):
         if tuple(got[b]) != dsp_oracle.basic_endpoint_detection(ref_in, 16000):
             bad.append((b, tuple(got[b]), dsp_oracle.basic_endpoint_detection(ref_in, 16000)))
     assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize('nfft,rate,winlen', [(512, 16000, 0.025), (1536, 48000, 0.03)])
+def test_degenerate_signals_through_the_fused_kernels(nfft, rate, winlen):
+    """All-zero clips (every filterbank energy and the frame energy hit the eps substitution of
+    base.py:26,30), DC, a full-scale alternating square wave, one impulse, digital silence with a
+    speech-like tail: fused kernels vs the oracle, dense and ragged, int16 and fp32."""
+    from features.batch import FeaturePlan
+    from oracle import dsp_oracle
+    cfg = dict(samplerate=rate, winlen=winlen, winstep=0.01, numcep=13, nfilt=26, nfft=nfft, lowfreq=0,
+               highfreq=None, preemph=0.97, ceplifter=22, appendEnergy=True)
+    plan = FeaturePlan(winfunc=np.hamming, **cfg)
+    n = rate // 2
+    rng = np.random.default_rng(3)
+    sigs = {
+        'zeros': np.zeros(n, dtype=np.int16),
+        'dc': np.full(n, 1234, dtype=np.int16),
+        'square': np.tile(np.array([32767, -32768], dtype=np.int16), n // 2),
+        'impulse': np.concatenate([np.zeros(n // 3, dtype=np.int16), [20000], np.zeros(n - n // 3 - 1, dtype=np.int16)]).astype(np.int16),
+        'silence_then_noise': np.concatenate([np.zeros(n // 2, dtype=np.int16),
+                                              np.round(500 * rng.standard_normal(n - n // 2)).astype(np.int16)]),
+    }
+    names = list(sigs)
+    for dtype in (np.int16, np.float32):
+        dense = np.stack([sigs[k] for k in names]).astype(dtype)
+        out, fo = plan.mfcc_batch(dense, delta_n=2)
+        flat = np.concatenate([sigs[k][:n - 7 * i] for i, k in enumerate(names)]).astype(dtype)
+        so = np.concatenate(([0], np.cumsum([n - 7 * i for i in range(len(names))]))).astype(np.int64)
+        out_r, fo_r = plan.mfcc_batch(flat, sample_offsets=so, delta_n=2)
+        assert np.isfinite(out).all() and np.isfinite(out_r).all()
+        for b, k in enumerate(names):
+            ref = dsp_oracle.mfcc_delta(dense[b].astype(np.float64), delta_n=2, winfunc=np.hamming, **cfg)
+            # exact-zero spectra: both sides are log(eps) constants; elsewhere the 1e-4 normwise bar.
+            # A bin that is exactly 0 in fp64 can be ~1e-30 in fp32 (and vice versa) only for the
+            # non-zero signals' leakage floor, where log() differences are bounded by the atol term.
+            assert normwise(out[fo[b]:fo[b + 1]], ref) <= TOLD, (dtype, k, normwise(out[fo[b]:fo[b + 1]], ref))
+            ref_r = dsp_oracle.mfcc_delta(flat[so[b]:so[b + 1]].astype(np.float64), delta_n=2, winfunc=np.hamming, **cfg)
+            assert normwise(out_r[fo_r[b]:fo_r[b + 1]], ref_r) <= TOLD, (dtype, k, "ragged")
