@@ -311,6 +311,38 @@ def test_fast1536_kernel(cfg, dtype):
         assert normwise(out_r[fo_r[b]:fo_r[b + 1]], ref) <= TOL, ('ragged', b, lens[b])
 
 
+@pytest.mark.parametrize('dtype', [np.float32, np.int16])
+def test_dense_batches_with_odd_length_take_the_fused_kernels(dtype):
+    """[B, N] batches whose N is not a multiple of 4 are handed to the fused kernels as ragged
+    batches with arithmetic offsets (built on the device): same numbers as the table-driven kernels,
+    and as fast as any other ragged batch.  MFCC at NFFT 512 and 1536, and the VAD features."""
+    from features.batch import EndpointPlan, FeaturePlan
+    from features import _native as nat
+    lib = nat.load()
+    for cfg, n in ((dict(CFG), 16001), (dict(samplerate=48000, winlen=0.03, winstep=0.01, numcep=13, nfilt=26,
+                                              nfft=1536, preemph=0.97, ceplifter=22, appendEnergy=True), 24003)):
+        plan = FeaturePlan(winfunc=np.hamming, **cfg)
+        x = _batch(71, 9, n, dtype=dtype)
+        out, fo = plan.mfcc_batch(x, delta_n=2)
+        try:
+            nat.check(lib.dsp_debug_force_generic(1))
+            gen, _ = plan.mfcc_batch(x, delta_n=2)
+        finally:
+            nat.check(lib.dsp_debug_force_generic(0))
+        assert normwise(out, gen) <= 5e-5
+        assert not np.array_equal(out, gen)            # really two different kernels
+        for b in (0, 8):
+            ref = dsp_oracle.mfcc_delta(x[b].astype(np.float64), delta_n=2, winfunc=np.hamming, **cfg)
+            assert normwise(out[fo[b]:fo[b + 1]], ref) <= TOL
+    ep = EndpointPlan(16000, 0.03, 0.01)
+    x = _batch(72, 7, 16001, dtype=dtype)
+    _, amp, zcr, fo = ep.detect_batch(x, return_feature=True)
+    for b in range(7):
+        frames = dsp_oracle.to_frames(x[b].astype(np.float64), 16000, t=0.03, step=0.01)
+        assert np.allclose(amp[fo[b]:fo[b + 1]], dsp_oracle.get_amplitude(frames), rtol=1e-6, atol=1e-9)
+        assert list(zcr[fo[b]:fo[b + 1]]) == list(dsp_oracle.get_zcr(frames))
+
+
 def test_odd_hop_uses_generic_kernel_and_matches():
     from features.batch import FeaturePlan
     from features import _native as nat
