@@ -104,30 +104,41 @@ GenericParams generic_params(const dsp_plan* p) {
     return P;
 }
 
-// sample_off[b] = b * n, frame_off[b] = b * t  (b = 0..n_utt)
-__global__ void iota_offsets_kernel(int64_t* __restrict__ sample_off, int64_t* __restrict__ frame_off,
-                                    int32_t n_utt, int64_t n, int64_t t) {
+// sample_off'[b] = (dense ? b * n : sample_off[b]) + shift, frame_off'[b] = dense ? b * t : frame_off[b]
+__global__ void offsets_view_kernel(const int64_t* __restrict__ src_sample, const int64_t* __restrict__ src_frame,
+                                    int64_t* __restrict__ sample_off, int64_t* __restrict__ frame_off,
+                                    int32_t n_utt, int64_t n, int64_t t, int64_t shift) {
     for (int b = blockIdx.x * blockDim.x + threadIdx.x; b <= n_utt; b += gridDim.x * blockDim.x) {
-        sample_off[b] = (int64_t)b * n;
-        frame_off[b] = (int64_t)b * t;
+        sample_off[b] = (src_sample ? src_sample[b] : (int64_t)b * n) + shift;
+        frame_off[b] = src_frame ? src_frame[b] : (int64_t)b * t;
     }
 }
 
-// A dense [B, N] batch whose N is not a multiple of 4 cannot use the dense instantiations of the
-// fused kernels (their 16-byte vectors would straddle utterances), but it is a perfectly good ragged
-// batch: write the arithmetic offset tables into a pooled workspace and describe it as one.
-// Returns nullptr (and leaves `bg` alone) if the workspace cannot be had.
-DspWorkspace* ragged_view_of_dense(BatchGeom& bg, hipStream_t st) {
+// The dense instantiations of the fused kernels need N % 4 == 0 (their 16-byte vectors must not
+// straddle utterances) and every fused kernel needs a 16-byte aligned buffer (8 for int16).  A batch
+// that violates either is still a perfectly good ragged batch of a buffer that starts a few samples
+// earlier: write offset tables (arithmetic for dense input, shifted copies otherwise) into a pooled
+// workspace and describe it that way.  `d_wave` is moved down to the aligned address.
+// Returns nullptr and changes nothing if no view is needed or the workspace cannot be had.
+DspWorkspace* fused_kernel_view(BatchGeom& bg, const void*& d_wave, int wave_dtype, hipStream_t st) {
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(d_wave);
+    const size_t elem = wave_dtype == DSP_WAVE_I16 ? 2 : 4;
+    const uintptr_t mis = addr % (4 * elem);               // bytes past the previous aligned vector
+    const bool odd_dense = bg.uniform_samples > 0 && (bg.uniform_samples % 4) != 0;
+    if ((mis == 0 && !odd_dense) || (mis % elem) != 0) return nullptr;
     DspWorkspace* w = dsp_workspace_pool().acquire(2 * ((size_t)bg.n_utt + 1) * sizeof(int64_t));
     if (!w) return nullptr;
     int64_t* so = static_cast<int64_t*>(w->ptr);
     int64_t* fo = so + bg.n_utt + 1;
     const int blocks = (bg.n_utt + 256) / 256 < 1024 ? (bg.n_utt + 256) / 256 : 1024;
-    iota_offsets_kernel<<<blocks, 256, 0, st>>>(so, fo, bg.n_utt, bg.uniform_samples, bg.uniform_frames);
+    const bool dense = bg.uniform_samples > 0;
+    offsets_view_kernel<<<blocks, 256, 0, st>>>(dense ? nullptr : bg.sample_off, dense ? nullptr : bg.frame_off, so, fo,
+                                                bg.n_utt, bg.uniform_samples, bg.uniform_frames, (int64_t)(mis / elem));
     bg.sample_off = so;
     bg.frame_off = fo;
     bg.uniform_samples = 0;
     bg.uniform_frames = 0;
+    d_wave = reinterpret_cast<const void*>(addr - mis);
     return w;
 }
 
@@ -359,14 +370,14 @@ int dsp_features_batch(const dsp_plan* plan, const void* d_wave, int wave_dtype,
         return fail(DSP_EINVAL, "n_frames_total %lld != n_utt*T (%d*%lld)", (long long)n_frames_total, n_utt, (long long)bg.uniform_frames);
     hipStream_t st = (hipStream_t)stream;
     if (out_kind == DSP_OUT_MFCC && !g_force_generic.load() && (plan->d_fast || plan->d_fast1536)) {
-        DspWorkspace* view = nullptr;
         BatchGeom fg = bg;
-        if (fg.uniform_samples > 0 && (fg.uniform_samples % 4) != 0) view = ragged_view_of_dense(fg, st);
+        const void* fw = d_wave;
+        DspWorkspace* view = fused_kernel_view(fg, fw, wave_dtype, st);
         int frc = 1;   // 1 = no fused kernel took it
-        if (fast512_applicable(plan, fg, d_wave, wave_dtype))
-            frc = fast512_launch(plan, d_wave, wave_dtype, fg, d_out, ld_out, st);
-        else if (fast1536_applicable(plan, fg, d_wave, wave_dtype))
-            frc = fast1536_launch(plan, d_wave, wave_dtype, fg, d_out, ld_out, st);
+        if (fast512_applicable(plan, fg, fw, wave_dtype))
+            frc = fast512_launch(plan, fw, wave_dtype, fg, d_out, ld_out, st);
+        else if (fast1536_applicable(plan, fg, fw, wave_dtype))
+            frc = fast1536_launch(plan, fw, wave_dtype, fg, d_out, ld_out, st);
         if (view && dsp_workspace_pool().release(view, st) != 0 && frc == DSP_OK) frc = DSP_EHIP;
         if (frc == DSP_OK) return DSP_OK;
         if (frc < 0) return fail(frc, "fused kernel launch failed");
@@ -465,11 +476,11 @@ int dsp_vad_features_batch(const void* d_wave, int wave_dtype, const int64_t* d_
     hipStream_t st = (hipStream_t)stream;
     const int tile = vad_tile_frames(frame_len, frame_step);
     if (!g_force_generic.load() && tile != 0) {
-        DspWorkspace* view = nullptr;
         BatchGeom fg = bg;
-        if (fg.uniform_samples > 0 && (fg.uniform_samples % 4) != 0) view = ragged_view_of_dense(fg, st);
-        const bool ok = vad_tile_applicable(fg, d_wave, wave_dtype, tile);
-        if (ok) rc = vad_tile_launch(tile, frame_len, frame_step, use_sq, fg, d_wave, wave_dtype, d_amp_sum, d_zcr, st);
+        const void* fw = d_wave;
+        DspWorkspace* view = fused_kernel_view(fg, fw, wave_dtype, st);
+        const bool ok = vad_tile_applicable(fg, fw, wave_dtype, tile);
+        if (ok) rc = vad_tile_launch(tile, frame_len, frame_step, use_sq, fg, fw, wave_dtype, d_amp_sum, d_zcr, st);
         if (view && dsp_workspace_pool().release(view, st) != 0 && ok && rc == DSP_OK) rc = DSP_EHIP;
         if (ok) {
             if (rc != DSP_OK) return fail(rc, "vad tile kernel launch failed");

@@ -12,9 +12,10 @@
  *     (NULL = default stream); every pointer prefixed d_ is DEVICE memory, h_ is host memory.
  *   - every function returns DSP_OK (0) or a negative DSP_E* code; dsp_last_error() gives the
  *     thread-local message.  Nothing falls back to a CPU path: without a GPU calls fail.
- *   - waveform buffers must start 16-byte aligned (hipMalloc / torch allocations are) for the
- *     specialised kernels to be used; unaligned buffers silently take the generic kernels (same
- *     results, slower).
+ *   - waveform buffers may start at any element-aligned address and dense batches may have any
+ *     length: what the fused kernels cannot take directly (a start that is not 16-byte aligned, a
+ *     dense length that is not a multiple of 4) is viewed as a ragged batch of the aligned buffer
+ *     underneath, with offset tables built on the device.
  *   - utterances are concatenated: sample_offsets[B+1] (int64) into the wave buffer,
  *     frame_offsets[B+1] (int64) into the [sum T_b, D] output (row-major, fp32).
  *   - no global mutable state besides the thread-local error string; a plan is immutable after

@@ -180,3 +180,46 @@ def test_ragged_calls_on_three_streams_at_once():
         torch.cuda.synchronize(dev)
         for j, (flat, lay, alone, out) in enumerate(jobs):
             assert torch.equal(out, alone), (rep, j)
+
+
+@pytest.mark.parametrize('tdtype', ['float32', 'int16'])
+def test_misaligned_device_views_take_the_fused_kernels(tdtype):
+    """Slices of a device tensor start at addresses that are not 16-byte aligned; the library views
+    them as ragged batches of the aligned buffer underneath (offsets shifted on the device) instead
+    of dropping to the table-driven kernel.  Results must not depend on the shift."""
+    import torch
+    from features.batch import FeaturePlan
+    from features import _native as nat
+    dev = torch.device('cuda', 0)
+    plan = FeaturePlan(winfunc=np.hamming, **CFG)
+    rng = np.random.default_rng(8)
+    B, N = 6, 8000
+    if tdtype == 'int16':
+        host = np.round(3000 * rng.standard_normal(B * N)).astype(np.int16)
+    else:
+        host = (0.25 * rng.standard_normal(B * N)).astype(np.float32)
+    lens = [8000, 1234, 16001, 7, 12000, 10758]
+    so = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+    assert so[-1] == B * N
+    base = torch.zeros(B * N + 8, dtype=getattr(torch, tdtype), device=dev)
+    ref_dense = ref_ragged = None
+    for shift in range(0, 5):
+        view = base[shift:shift + B * N]
+        view.copy_(torch.from_numpy(host))
+        dense, _ = plan.mfcc_batch(view.view(B, N), delta_n=2)
+        ragged, _ = plan.mfcc_batch(view, sample_offsets=so, delta_n=2)
+        if shift == 0:
+            ref_dense, ref_ragged = dense.clone(), ragged.clone()
+            try:
+                nat.check(nat.load().dsp_debug_force_generic(1))
+                gen, _ = plan.mfcc_batch(view.view(B, N), delta_n=2)
+            finally:
+                nat.check(nat.load().dsp_debug_force_generic(0))
+            assert not torch.equal(gen, dense)
+            continue
+        # shifted views run the ragged instantiation: equal to the aligned ragged run bit for bit,
+        # and to the dense run up to the contraction noise documented in DESIGN.md
+        assert torch.equal(ragged, ref_ragged), shift
+        err = (dense - ref_dense).abs().max().item() / ref_dense.abs().max().item()
+        assert err <= 2e-5, (shift, err)
+        assert not torch.equal(dense, gen)                       # still not the table-driven kernel
