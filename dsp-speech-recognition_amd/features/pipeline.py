@@ -17,7 +17,14 @@ from __future__ import annotations
 import numpy as np
 
 from . import _native as nat
-from .batch import EndpointPlan, FeaturePlan, _BatchLayout
+from .batch import EndpointPlan, FeaturePlan, _BatchLayout, _is_device_tensor, _wave_dtype_of
+
+
+class _Borrowed:
+    """Device memory owned by the caller (a tensor); only the address is kept."""
+
+    def __init__(self, ptr):
+        self.ptr = int(ptr)
 
 
 def _ones(x):
@@ -35,7 +42,8 @@ class VadMfccPipeline:
         self.features = FeaturePlan(**mfcc_kwargs)
 
     def run(self, waves, sample_offsets, delta_n=2, download=True):
-        """waves: 1-D host array (int16 or float) of concatenated utterances.
+        """waves: 1-D host array (int16 or float) or torch-ROCm tensor (int16 / float32) of concatenated
+        utterances.
         Returns (features [sum T_b, D] fp32, frame_offsets [B+1], endpoints [B, 2] in samples);
         with ``download=False`` the features stay on the device and the first element is the
         (DeviceBuffer, _BatchLayout) pair of the result instead."""
@@ -43,8 +51,14 @@ class VadMfccPipeline:
         lib = nat.load()
         so = np.ascontiguousarray(sample_offsets, dtype=np.int64)
         B = len(so) - 1
-        wave, dtype = nat.as_wave(np.asarray(waves).reshape(-1))
-        d_wave = nat.device_array('batch_wave', wave)
+        if _is_device_tensor(waves):                # torch-ROCm tensor: nothing crosses PCIe
+            if not waves.is_contiguous():
+                waves = waves.contiguous()
+            dtype = _wave_dtype_of(waves)
+            d_wave = _Borrowed(waves.data_ptr())
+        else:
+            wave, dtype = nat.as_wave(np.asarray(waves).reshape(-1))
+            d_wave = nat.device_array('batch_wave', wave)
 
         # 1. endpoints (frame indices -> sample indices exactly as endpoint.py:64)
         ep = self.endpoint

@@ -80,6 +80,10 @@ def test_model_feature_batch_matches_reference_pipeline(golden):
     so = np.concatenate(([0], np.cumsum([len(c) for c in clips]))).astype(np.int64)
     inp, len0, ends = ModelFeatureBatch(rate=44100).run(np.concatenate(clips), so)
     assert inp.shape == (200, 3, 39)
+    # the same clips already resident on the device (no PCIe traffic): identical result
+    import torch
+    inp_d, len_d, ends_d = ModelFeatureBatch(rate=44100).run(torch.from_numpy(np.concatenate(clips)).cuda(), so)
+    assert torch.equal(inp_d, inp) and np.array_equal(len_d, len0) and np.array_equal(ends_d, ends)
     got = inp.cpu().numpy()
     # utterance 0: the reference itself
     for key, col in (('m0', 0), ('m1', 13), ('m2', 26)):
