@@ -227,3 +227,30 @@ def test_misaligned_device_views_take_the_fused_kernels(tdtype):
         err = (dense - ref_dense).abs().max().item() / ref_dense.abs().max().item()
         assert err <= 2e-5, (shift, err)
         assert not torch.equal(dense, gen)                       # still not the table-driven kernel
+
+
+def test_dense_step_is_hip_graph_capturable():
+    """The dense path allocates nothing and never synchronises, so it can be captured into a HIP
+    graph (after one eager warm-up call, which raises the kernel's dynamic-LDS limit) and replayed."""
+    import torch
+    from features.batch import FeaturePlan
+    from features import _native as nat
+    dev = torch.device('cuda', 0)
+    plan = FeaturePlan(winfunc=np.hamming, **CFG)
+    B, N = 64, 16000
+    x = 0.25 * torch.randn((B, N), device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+    lay = plan.layout(np.empty((B, N), dtype=np.float32))
+    eager = torch.empty((lay.total_frames, 39), device=dev)
+    plan.run_raw(x.data_ptr(), nat.WAVE_F32, lay, eager.data_ptr(), 2, torch.cuda.current_stream(dev))
+    torch.cuda.synchronize(dev)
+    out = torch.zeros_like(eager)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(dev)
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            plan.run_raw(x.data_ptr(), nat.WAVE_F32, lay, out.data_ptr(), 2, torch.cuda.current_stream(dev))
+    for _ in range(3):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize(dev)
+        assert torch.equal(out, eager)
