@@ -11,12 +11,15 @@
 //   * each 512-point FFT is split m = 16 n1 + n2 exactly like the NFFT = 512 kernel: lane c owns
 //     column n2 = c -> one in-register complex FFT32 over n1, twiddle W512^(c k1), exchange through
 //     LDS (two rounds of 16 rows, XOR-swizzled 16-byte slots, conflict-free both ways), then lane c
-//     owns rows k1 = c and c + 16 -> two in-register FFT16 over n2 -> Y[k1 + 32 k2];
+//     owns rows k1 = c and c + 16 -> two in-register FFT16 over n2 -> Y[k1 + 32 k2]; the real y_0
+//     takes a cheaper route (FFT16 of packed pairs + untangle -> 17 rows, f1536_rfft512);
 //   * all power values stay in registers until both FFTs are done, so the per-wave LDS region is
 //     reused three times (staged samples -> exchange buffer -> one 776-float spectrum row per
 //     frame) and 8 waves fit a CU next to ~30 KB of tables;
-//   * |X|^2 / 1536 -> LDS row -> table-driven sparse mel (lane c owns filters c, c + 16, ...) ->
-//     log -> DCT*lifter partial sums -> 4-step DPP all-reduce over the frame's 16 lanes -> store.
+//   * |X|^2 / 1536 -> LDS row -> table-driven sparse mel: the filters are cut into 64 equal slots,
+//     lane s sums slot s for all four frames, the pieces of a filter are added up through LDS ->
+//     log -> DCT*lifter partial sums (lane c owns filters c, c + 16, ...) -> 4-step DPP
+//     all-reduce over the frame's 16 lanes -> store.
 // Samples are read from HBM once per wave (3 S + 1536 of them, 16 B per lane), pre-emphasised on
 // the fly and staged in LDS exactly as in kernels_fast512.h (whose staging helpers are reused).
 #pragma once
