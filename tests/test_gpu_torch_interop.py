@@ -227,6 +227,19 @@ def test_misaligned_device_views_take_the_fused_kernels(tdtype):
         err = (dense - ref_dense).abs().max().item() / ref_dense.abs().max().item()
         assert err <= 2e-5, (shift, err)
         assert not torch.equal(dense, gen)                       # still not the table-driven kernel
+    # the same for the VAD features (amplitude sums / zero crossings) and the endpoints they lead to
+    from features.batch import EndpointPlan
+    ep = EndpointPlan(16000, 0.03, 0.01)
+    want = None
+    for shift in range(0, 4):
+        view = base[shift:shift + B * N]
+        view.copy_(torch.from_numpy(host))
+        got = ep.detect_batch(view, sample_offsets=so, return_feature=True)
+        if want is None:
+            want = got
+            continue
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2])
+        assert np.allclose(got[1], want[1], rtol=1e-12, atol=0)
 
 
 def test_dense_step_is_hip_graph_capturable():
