@@ -93,3 +93,25 @@ def test_config4_share_ragged():
         assert (int(ends[b, 0]), int(ends[b, 1])) == (l, min(r, len(sigs[b]))), b
         ref = dsp_oracle.mfcc_delta(sigs[b][l:r].astype(np.float64), delta_n=2, winfunc=np.hamming, **CFG)
         assert normwise(feats[fo[b]:fo[b + 1]], ref) <= TOL, b
+
+
+def test_config3_count_ragged_100k(plan):
+    """configs[2]'s utterance count in ONE ragged launch: 100 000 utterances of 1..9000 samples
+    (200 distinct clips repeated; group / tile tables with 100 001 entries).  Every repeat must equal
+    the first bitwise, and the first must equal a separate 200-utterance launch."""
+    rng = np.random.default_rng(2002)
+    distinct, reps = 200, 500
+    sigs = [np.round(3000 * rng.standard_normal(int(rng.integers(1, 9000)))).astype(np.int16) for _ in range(distinct)]
+    lens = np.array([len(s) for s in sigs] * reps)
+    so = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    flat = np.tile(np.concatenate(sigs), reps)
+    out, fo = plan.mfcc_batch(flat, sample_offsets=so, delta_n=2)
+    assert len(fo) == distinct * reps + 1 and out.shape == (fo[-1], 39) and np.isfinite(out).all()
+    per = fo[distinct]
+    for r in range(1, reps):
+        assert np.array_equal(out[r * per:(r + 1) * per], out[:per]), r
+    small, _ = plan.mfcc_batch(np.concatenate(sigs), sample_offsets=so[:distinct + 1], delta_n=2)
+    assert np.array_equal(small, out[:per])
+    b = 17
+    ref = dsp_oracle.mfcc_delta(sigs[b].astype(np.float64), delta_n=2, winfunc=np.hamming, **CFG)
+    assert normwise(out[fo[b]:fo[b + 1]], ref) <= TOL
