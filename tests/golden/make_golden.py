@@ -36,7 +36,8 @@ def load_reference():
     for name in ('preemphasis', 'framesig', 'to_frames', 'magspec', 'powspec', 'logpowspec',
                  'deframesig', 'get_filterbanks', 'fbank', 'mfcc', 'lifter', 'delta',
                  'get_amplitude', 'get_zcr', 'amplitude_rule', 'zcr_rule', 'amplitude_feature',
-                 'basic_endpoint_detection', 'robust_endpoint_detection'):
+                 'basic_endpoint_detection', 'robust_endpoint_detection', 'downsampling', 'center_clip',
+                 'pitch_detect_frame_sr', 'pitch_detect_sr'):
         setattr(api, name, getattr(features, name))
     # NOTE: ``features.preemphasis`` resolves to preprocess.preemphasis (star-import order); the
     # sigproc one is what fbank calls.  They are identical; record the sigproc one.

@@ -181,6 +181,11 @@ for i, spec in enumerate((('vad', 90, 25600), ('vad', 91, 32000), ('bursts', 92,
 _add('model_feat_44k', 'model_feature_extract_mfcc', ('vad', 70, 52920, 44100, 0.7), rate=44100)
 _add('model_feat_48k', 'model_feature_extract_mfcc', ('vad', 71, 60000, 48000, 0.6), rate=48000)
 
+# next-row f-4: pitch scores (pitch.pitch_detect_sr as model.py:92 calls it: winlen = cfg.frame, step = cfg.step)
+_add('pitch_sr_16k', 'pitch_detect_sr', ('vad', 95, 19200, 16000, 0.7), rate=16000, winlen=0.03, step=0.01)
+_add('pitch_sr_44k', 'pitch_detect_sr', ('vad', 96, 39690, 44100, 0.6), rate=44100, winlen=0.03, step=0.01)
+_add('pitch_sr_harm', 'pitch_detect_sr', ('harmonic', 97, 12000), rate=16000, winlen=0.0512, step=0.01)
+
 # deframesig (API-surface extra)
 _add('deframesig', 'deframesig', ('white', 80, 2000), frame_len=400, frame_step=160,
      winfunc='hamming')
@@ -266,6 +271,13 @@ def run_case(case, api):
         (m0, m1, m2), n = api.model_pipeline(x, kw['rate'])
         return {'m0': np.asarray(m0), 'm1': np.asarray(m1), 'm2': np.asarray(m2),
                 'len': np.array([n], dtype=np.int64)}
+    if fn == 'pitch_detect_sr':
+        down = np.asarray(api.downsampling(x, kw['rate'], 10000))
+        frames = api.to_frames(down, 10000, kw['winlen'], kw['step'])
+        scores = np.array([api.pitch_detect_frame_sr(api.center_clip(fr, False), 10000) for fr in frames],
+                          dtype=np.float64)
+        pitch, _ = api.pitch_detect_sr(x, kw['rate'], winlen=kw['winlen'], step=kw['step'])
+        return {'down': down.astype(np.float64), 'scores': scores, 'pitch': np.asarray(pitch, dtype=np.float64)}
     if fn == 'deframesig':
         frames = api.framesig(x, kw['frame_len'], kw['frame_step'], kw['winfunc'])
         return {'out': np.asarray(api.deframesig(frames, len(x), kw['frame_len'], kw['frame_step'],

@@ -46,6 +46,8 @@ def api():
 
 @pytest.mark.parametrize('case', CASES, ids=[c['name'] for c in CASES])
 def test_gpu_matches_reference(case, golden, api):
+    if case['fn'] == 'pitch_detect_sr' and not hasattr(api, 'pitch_detect_sr'):
+        pytest.skip('pitch scores are not on the device yet (DESIGN.md section 9)')
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         res = run_case(case, api)
