@@ -14,6 +14,7 @@
 #include "kernels_fast512.h"
 #include "kernels_fast1536.h"
 #include "kernels_vad.h"
+#include "kernels_pitch.h"
 
 namespace {
 
@@ -524,6 +525,28 @@ int dsp_model_finalize_batch(const float* d_mfcc, int64_t ld_in, const int64_t* 
     if (lds > 64 * 1024) return fail(DSP_EINVAL, "max_len * C too large for the LDS tile (%zu bytes)", lds);
     model_finalize_kernel<<<n_utt, 256, lds, (hipStream_t)stream>>>(d_mfcc, ld_in, d_frame_offsets, n_utt, C, N,
                                                                    max_len, d_out, d_len0);
+    HIP_TRY(hipGetLastError());
+    return DSP_OK;
+}
+
+int dsp_pitch_scores_batch(const float* d_sig, const int64_t* d_sample_offsets, const int64_t* d_frame_offsets,
+                           int32_t n_utt, int64_t n_frames_total, int64_t uniform_samples, int32_t frame_len,
+                           int32_t frame_step, const float* d_taps, int32_t center_clip, int32_t lag_min,
+                           int32_t lag_max, float* d_scores, void* stream) {
+    if (!d_taps || !d_scores) return fail(DSP_EINVAL, "dsp_pitch_scores_batch: NULL taps/output");
+    if (frame_len <= 0 || frame_len > PITCH_MAX_L || frame_step <= 0)
+        return fail(DSP_EINVAL, "need 0 < frame_len <= %d and frame_step > 0", PITCH_MAX_L);
+    if (lag_min < 0 || lag_max <= lag_min) return fail(DSP_EINVAL, "need 0 <= lag_min < lag_max");
+    int rc = check_geom(d_sig, DSP_WAVE_F32, d_sample_offsets, d_frame_offsets, n_utt, n_frames_total, uniform_samples);
+    if (rc != DSP_OK) return rc;
+    if (n_frames_total > 0x7fffffff) return fail(DSP_EINVAL, "too many frames for one launch");
+    BatchGeom bg = make_geom(d_sample_offsets, d_frame_offsets, n_utt, n_frames_total, uniform_samples, frame_len, frame_step);
+    int P = 1;
+    while (P < frame_len) P <<= 1;
+    const size_t lds = ((size_t)P + (size_t)((frame_len + 3) & ~3) + 3 * (size_t)frame_len) * sizeof(float);
+    pitch_scores_kernel<<<(int)n_frames_total, PITCH_THREADS, lds, (hipStream_t)stream>>>(
+        d_sig, bg, frame_len, frame_step, P, reinterpret_cast<const float2*>(d_taps), center_clip ? 1 : 0, lag_min,
+        lag_max - lag_min, d_scores);
     HIP_TRY(hipGetLastError());
     return DSP_OK;
 }

@@ -7,13 +7,15 @@ and return types as features/{sigproc,base,endpoint,preprocess}.py; the arithmet
 hand-written HIP kernels (gfx950) behind a ctypes C ABI (include/dsp_frontend.h).
 
 Unlike the reference's ``features/__init__.py`` this import has no side effects (no ./log/
-directory, no matplotlib / sklearn import), and the pitch module is out of scope.
+directory, no matplotlib / sklearn import); of the pitch module only the score path is here.
 There is no CPU fallback: without the built library or without a GPU every compute call raises.
 """
 from .base import *  # noqa: F401,F403
 from .sigproc import *  # noqa: F401,F403
 from .endpoint import *  # noqa: F401,F403
 from .preprocess import *  # noqa: F401,F403
-from . import base, sigproc, endpoint, preprocess, batch, pipeline  # noqa: F401
+from .pitch import (center_clip, max_pitch, pitch_detect_frame_sr, pitch_detect_sr,  # noqa: F401
+                    robust_max_pitch, smooth, window)
+from . import base, sigproc, endpoint, preprocess, pitch, batch, pipeline  # noqa: F401
 from .batch import FeaturePlan, EndpointPlan  # noqa: F401
 from .pipeline import VadMfccPipeline  # noqa: F401

@@ -200,6 +200,25 @@ int dsp_model_finalize_batch(const float* d_mfcc, int64_t ld_in, const int64_t* 
                              int32_t n_utt, int32_t C, int32_t N, int32_t max_len, float* d_out,
                              int32_t* d_len0, void* stream);
 
+/* ---- pitch scores ------------------------------------------------------ */
+/*
+ * Per frame of the (already 10 kHz) signal, rectangular frames of frame_len / hop frame_step as
+ * sigproc.to_frames cuts them:
+ *   centre clipping at the median of the non-negative samples (if center_clip != 0)
+ *                                                         pitch.center_clip      pitch.py:145-155
+ *   y = convolve(frame, taps)[:frame_len], f = |y|        sigproc.window         sigproc.py:22-46
+ *   scores[t, n - lag_min] = sum_i f[i] f[i+n] / (frame_len - n), lag_min <= n < lag_max
+ *                                                         sigproc.acr            sigproc.py:48-53
+ * i.e. pitch.pitch_detect_frame_sr (pitch.py:112-132) for every frame of pitch.pitch_detect_sr
+ * (pitch.py:96-107).  d_sig: fp32; d_taps: frame_len complex taps (re, im interleaved), built by the
+ * host in fp64; d_scores: [sum T_b, lag_max - lag_min] fp32.  frame_len <= 1024.
+ */
+int dsp_pitch_scores_batch(const float* d_sig, const int64_t* d_sample_offsets,
+                           const int64_t* d_frame_offsets, int32_t n_utt, int64_t n_frames_total,
+                           int64_t uniform_samples, int32_t frame_len, int32_t frame_step,
+                           const float* d_taps, int32_t center_clip, int32_t lag_min, int32_t lag_max,
+                           float* d_scores, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -140,3 +140,47 @@ def test_degenerate_signals_through_the_fused_kernels(nfft, rate, winlen):
             assert normwise(out[fo[b]:fo[b + 1]], ref) <= TOLD, (dtype, k, normwise(out[fo[b]:fo[b + 1]], ref))
             ref_r = dsp_oracle.mfcc_delta(flat[so[b]:so[b + 1]].astype(np.float64), delta_n=2, winfunc=np.hamming, **cfg)
             assert normwise(out_r[fo_r[b]:fo_r[b + 1]], ref_r) <= TOLD, (dtype, k, "ragged")
+
+
+def test_pitch_scores_batch_and_tracks_vs_oracle():
+    """Row f-4: the per-frame pitch scores (centre clip -> complex band-pass FIR -> |.| -> 180
+    autocorrelation lags) for a ragged batch of 10 kHz signals in one launch, and the pitch tracks
+    of pitch_detect_sr on raw clips, against the oracle (pitch.py:96-132)."""
+    import features
+    from features import pitch as gp
+    from oracle import dsp_oracle
+    rng = np.random.default_rng(61)
+    clips = []
+    for i in range(10):
+        n = int(rng.integers(2000, 9000))
+        t = np.arange(n) / 10000.0
+        f0 = rng.uniform(80, 400)
+        x = sum(np.sin(2 * np.pi * f0 * h * t + rng.uniform(0, 6)) / h for h in range(1, 6))
+        clips.append(np.round(4000 * x * np.hanning(n) + 30 * rng.standard_normal(n)))
+    clips.append(np.zeros(700))                       # all zero: median 0, every score 0
+    clips.append(-np.abs(clips[0][:900]) - 1.0)       # no non-negative sample: NaN clip level -> zeros
+    clips.append(clips[1][:150])                      # shorter than one frame (zero padded)
+    so = np.concatenate(([0], np.cumsum([len(c) for c in clips]))).astype(np.int64)
+    scores, fo = gp.frame_scores_batch(np.concatenate(clips), so, 300, 100)
+    assert scores.shape == (fo[-1], 180)
+    for b, c in enumerate(clips):
+        frames = dsp_oracle.to_frames(c, 10000, 0.03, 0.01)
+        assert fo[b + 1] - fo[b] == len(frames)
+        ref = np.stack([dsp_oracle.pitch_frame_scores(dsp_oracle.center_clip(fr, False), 10000) for fr in frames])
+        got = scores[fo[b]:fo[b + 1]]
+        if np.max(np.abs(ref)) == 0:
+            assert np.max(np.abs(got)) == 0, b
+        else:
+            assert normwise(got, ref) <= 1e-4, (b, normwise(got, ref))
+    # whole tracks from raw clips at two rates: identical Hz values frame by frame
+    for rate in (16000, 44100):
+        n = int(0.6 * rate)
+        t = np.arange(n) / rate
+        sig = np.round(3000 * (np.sin(2 * np.pi * 140 * t) + 0.5 * np.sin(2 * np.pi * 280 * t)) * np.hanning(n)
+                       + 40 * rng.standard_normal(n)).astype(np.int16)
+        got, frames = features.pitch_detect_sr(sig, rate, winlen=0.03, step=0.01)
+        ref, ref_frames = dsp_oracle.pitch_detect_sr(sig, rate, winlen=0.03, step=0.01)
+        assert np.array_equal(np.asarray(frames), ref_frames)
+        assert len(got) == len(ref)
+        same = np.isclose(got, ref, rtol=1e-9, atol=0)
+        assert same.mean() >= 0.98, (rate, same.mean())     # an arg-max over fp32 scores may flip on a near tie

@@ -36,7 +36,8 @@ def api():
     for name in ('preemphasis', 'framesig', 'to_frames', 'magspec', 'powspec', 'logpowspec', 'deframesig',
                  'get_filterbanks', 'fbank', 'mfcc', 'lifter', 'delta', 'get_amplitude', 'get_zcr',
                  'amplitude_rule', 'zcr_rule', 'amplitude_feature', 'basic_endpoint_detection',
-                 'robust_endpoint_detection'):
+                 'robust_endpoint_detection', 'downsampling', 'center_clip', 'pitch_detect_frame_sr',
+                 'pitch_detect_sr'):
         setattr(a, name, getattr(features, name))
     a.preemphasis = features.sigproc.preemphasis
     from features.model_glue import model_pipeline
