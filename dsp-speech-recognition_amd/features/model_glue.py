@@ -38,6 +38,33 @@ def feature_extract_mfcc(sound, rate, nfft=1536):
     return (m0, m1, m2), min(len(m0), 200)
 
 
+def deviation(arr, smooth=1):
+    """model.py:29-33: first difference at distance ``smooth``."""
+    arr = np.asarray(arr, dtype=np.float64)
+    return arr[smooth:] - arr[:len(arr) - smooth]
+
+
+def feature_extract_pitch(sound, rate):
+    """model.py:90-95, the optional pitch stream (cfg.use_pitch): pitch track / 150 and its
+    first difference, both [T, 1]."""
+    from .pitch import pitch_detect_sr
+    cfg = _endpoint.cfg
+    pitch0, _ = pitch_detect_sr(np.asarray(sound).reshape(-1), rate, winlen=cfg.frame, step=cfg.step)
+    pitch0 = np.array(pitch0).reshape(-1, 1) / 150
+    return [pitch0.reshape(-1, 1), deviation(pitch0).reshape(-1, 1)]
+
+
+def feature_extract_timespace(sound, rate):
+    """model.py:97-101, the optional amplitude stream (cfg.use_timefeat): z-scored frame amplitude
+    (population std, zero -> 1 as sklearn.scale) and its first difference, both [T, 1]."""
+    cfg = _endpoint.cfg
+    a = np.asarray(_endpoint.amplitude_feature(np.asarray(sound).reshape(-1), rate, winlen=cfg.frame, step=cfg.step),
+                   dtype=np.float64)
+    sd = a.std()
+    amp0 = ((a - a.mean()) / (sd if sd != 0 else 1.0)).reshape(-1, 1)
+    return [amp0, deviation(amp0).reshape(-1, 1)]
+
+
 def pad200(b):
     """model.py:35-39: zero-pad or truncate a [T, D] stream to exactly 200 frames."""
     b = np.asarray(b)

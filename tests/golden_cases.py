@@ -186,6 +186,9 @@ _add('pitch_sr_16k', 'pitch_detect_sr', ('vad', 95, 19200, 16000, 0.7), rate=160
 _add('pitch_sr_44k', 'pitch_detect_sr', ('vad', 96, 39690, 44100, 0.6), rate=44100, winlen=0.03, step=0.01)
 _add('pitch_sr_harm', 'pitch_detect_sr', ('harmonic', 97, 12000), rate=16000, winlen=0.0512, step=0.01)
 
+# model.py:90-101: the optional pitch / amplitude streams (cfg.use_pitch, cfg.use_timefeat)
+_add('model_side_streams', 'model_side_streams', ('vadf', 98, 24000), rate=16000)
+
 # deframesig (API-surface extra)
 _add('deframesig', 'deframesig', ('white', 80, 2000), frame_len=400, frame_step=160,
      winfunc='hamming')
@@ -278,6 +281,11 @@ def run_case(case, api):
                           dtype=np.float64)
         pitch, _ = api.pitch_detect_sr(x, kw['rate'], winlen=kw['winlen'], step=kw['step'])
         return {'down': down.astype(np.float64), 'scores': scores, 'pitch': np.asarray(pitch, dtype=np.float64)}
+    if fn == 'model_side_streams':
+        p0, p1 = api.model_feature_extract_pitch(x, kw['rate'])
+        a0, a1 = api.model_feature_extract_timespace(x, kw['rate'])
+        return {'pitch0': np.asarray(p0, dtype=np.float64), 'pitch1': np.asarray(p1, dtype=np.float64),
+                'amp0': np.asarray(a0, dtype=np.float64), 'amp1': np.asarray(a1, dtype=np.float64)}
     if fn == 'deframesig':
         frames = api.framesig(x, kw['frame_len'], kw['frame_step'], kw['winfunc'])
         return {'out': np.asarray(api.deframesig(frames, len(x), kw['frame_len'], kw['frame_step'],

@@ -40,8 +40,10 @@ def api():
                  'pitch_detect_sr'):
         setattr(a, name, getattr(features, name))
     a.preemphasis = features.sigproc.preemphasis
-    from features.model_glue import model_pipeline
+    from features.model_glue import feature_extract_pitch, feature_extract_timespace, model_pipeline
     a.model_pipeline = model_pipeline
+    a.model_feature_extract_pitch = feature_extract_pitch
+    a.model_feature_extract_timespace = feature_extract_timespace
     return a
 
 
