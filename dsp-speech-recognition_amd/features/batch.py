@@ -31,7 +31,9 @@ def _stream_ptr(stream):
 class _BatchLayout:
     """Sample/frame offsets of one batch on host and (for ragged batches) on the device."""
 
-    def __init__(self, L, S, n_utt, uniform_samples=0, sample_offsets=None):
+    def __init__(self, L, S, n_utt, uniform_samples=0, sample_offsets=None, scratch=None):
+        """``scratch``: name of a library-owned scratch slot for the device copies of the offsets (for
+        layouts that live for one call; avoids two hipMalloc / hipFree pairs per call)."""
         self.n_utt = int(n_utt)
         self.uniform_samples = int(uniform_samples)
         if self.uniform_samples > 0:
@@ -44,8 +46,12 @@ class _BatchLayout:
             assert self.sample_offsets.shape == (self.n_utt + 1,)
             self.frame_offsets = nat.frame_offsets(self.sample_offsets, L, S)
             self.T = 0
-            self.d_sample = nat.DeviceBuffer(self.sample_offsets.nbytes).upload(self.sample_offsets)
-            self.d_frame = nat.DeviceBuffer(self.frame_offsets.nbytes).upload(self.frame_offsets)
+            if scratch is not None:
+                self.d_sample = nat.device_array(scratch + '_so', self.sample_offsets)
+                self.d_frame = nat.device_array(scratch + '_fo', self.frame_offsets)
+            else:
+                self.d_sample = nat.DeviceBuffer(self.sample_offsets.nbytes).upload(self.sample_offsets)
+                self.d_frame = nat.DeviceBuffer(self.frame_offsets.nbytes).upload(self.frame_offsets)
         self.total_frames = int(self.frame_offsets[-1])
         self.total_samples = int(self.sample_offsets[-1])
 

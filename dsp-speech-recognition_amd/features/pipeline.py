@@ -62,7 +62,7 @@ class VadMfccPipeline:
 
         # 1. endpoints (frame indices -> sample indices exactly as endpoint.py:64)
         ep = self.endpoint
-        lay = _BatchLayout(ep.L, ep.S, B, sample_offsets=so)
+        lay = _BatchLayout(ep.L, ep.S, B, sample_offsets=so, scratch='pipe_vad')
         nf = lay.total_frames
         d_amp = nat.SCRATCH.get('ep_amp', nf * 8)
         d_zcr = nat.SCRATCH.get('ep_zcr', nf * 4)
@@ -87,7 +87,7 @@ class VadMfccPipeline:
 
         # 3. features of the trimmed clips (ragged layout)
         fp = self.features
-        flay = _BatchLayout(fp.L, fp.S, B, sample_offsets=dst_off)
+        flay = _BatchLayout(fp.L, fp.S, B, sample_offsets=dst_off, scratch='pipe_mfcc')
         D = fp.width(delta_n)
         d_out = nat.SCRATCH.get('batch_out', flay.total_frames * D * 4)
         fp.run_raw(d_trim.ptr, nat.WAVE_F32, flay, d_out.ptr, delta_n, None)
