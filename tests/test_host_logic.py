@@ -131,3 +131,33 @@ def test_product_does_not_import_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dirpath, f)).read()
                 assert 'oracle' not in src.replace('no oracle', ''), f'{f} mentions the oracle'
+
+
+def test_pitch_host_helpers_match_oracle():
+    """The host-side pieces of the pitch path (decimation indices, centre clipping, band-pass taps,
+    in-place smoothing, octave repair) against the oracle restatements pinned to the reference."""
+    from features import pitch as gp
+    from features.preprocess import downsampling
+    from oracle import dsp_oracle
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal(7001)
+    for rate in (10000, 11025, 16000, 22050, 44100, 48000):
+        assert np.array_equal(downsampling(x, rate, 10000), dsp_oracle.downsampling(x, rate, 10000)), rate
+    literal, ticks = [], -1                      # the reference's loop, spelled out once
+    for i in range(len(x)):
+        if i * 10000 / 44100 > ticks + 1e-8:
+            ticks += 1
+            literal.append(i)
+    assert np.array_equal(downsampling(x, 44100, 10000), x[literal])
+    fr = np.round(300 * rng.standard_normal(300))
+    for binary in (True, False):
+        assert np.array_equal(gp.center_clip(fr, binary), dsp_oracle.center_clip(fr, binary))
+    assert np.array_equal(gp.center_clip(-np.abs(fr) - 1, False), np.zeros(300))    # no non-negative sample
+    assert np.allclose(gp.bandpass_taps(300, 10000, 50, 900, 'hamming'),
+                       dsp_oracle.bandpass_taps(300, 10000, 50, 900, 'hamming'), rtol=0, atol=0)
+    assert np.allclose(gp.window(fr, 10000, 50, 900, 'hamming'), dsp_oracle.window(fr, 10000, 50, 900, 'hamming'),
+                       rtol=0, atol=1e-12)
+    g = rng.random((37, 180))
+    assert np.array_equal(np.asarray(gp.smooth(g, 2)), dsp_oracle.smooth(g, 2))
+    assert gp.robust_max_pitch(g) == dsp_oracle.robust_max_pitch(g)
+    assert gp.max_pitch(g[:3]) == dsp_oracle.max_pitch(g[:3])
