@@ -543,6 +543,22 @@ int dsp_pitch_scores_batch(const float* d_sig, const int64_t* d_sample_offsets, 
     BatchGeom bg = make_geom(d_sample_offsets, d_frame_offsets, n_utt, n_frames_total, uniform_samples, frame_len, frame_step);
     int P = 1;
     while (P < frame_len) P <<= 1;
+    // register-blocked kernel (one wave per frame) where its shape constraints hold
+    const int n_lags = lag_max - lag_min;
+    const int W = frame_len <= 384 ? 3 : (frame_len <= 512 ? 4 : 0);
+    if (W != 0 && (lag_min % 4) == 0 && n_lags <= 256 && lag_max + 8 <= PITCH2_GUARD && !g_force_generic.load()) {
+        const int Lp = (frame_len + W - 1) / W * W;
+        const size_t lds2 = (2 * (size_t)Lp + 2 * (size_t)Lp + (size_t)Lp + PITCH2_GUARD) * sizeof(float);
+        const float2* tp = reinterpret_cast<const float2*>(d_taps);
+        if (W == 3)
+            pitch_scores_kernel_v2<3><<<(int)n_frames_total, 64, lds2, (hipStream_t)stream>>>(
+                d_sig, bg, frame_len, frame_step, P, tp, center_clip ? 1 : 0, lag_min, n_lags, d_scores);
+        else
+            pitch_scores_kernel_v2<4><<<(int)n_frames_total, 64, lds2, (hipStream_t)stream>>>(
+                d_sig, bg, frame_len, frame_step, P, tp, center_clip ? 1 : 0, lag_min, n_lags, d_scores);
+        HIP_TRY(hipGetLastError());
+        return DSP_OK;
+    }
     const size_t lds = ((size_t)P + (size_t)((frame_len + 3) & ~3) + 3 * (size_t)frame_len) * sizeof(float);
     pitch_scores_kernel<<<(int)n_frames_total, PITCH_THREADS, lds, (hipStream_t)stream>>>(
         d_sig, bg, frame_len, frame_step, P, reinterpret_cast<const float2*>(d_taps), center_clip ? 1 : 0, lag_min,

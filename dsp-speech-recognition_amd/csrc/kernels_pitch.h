@@ -106,3 +106,163 @@ __global__ __launch_bounds__(PITCH_THREADS) void pitch_scores_kernel(
         scores[g * n_lags + q] = acc;
     }
 }
+
+// Register-blocked variant, one wavefront per frame.  Every lane owns W consecutive FIR outputs at
+// the bottom of the frame and W at the top (so all lanes do the same work), keeps the 2 W samples it
+// needs in a register ring and reads one new sample per chunk and tap: 3 LDS reads per 4 W
+// multiply-adds instead of 3 per 4.  Indices below zero fall into a zeroed guard band, so the tap
+// loop is uniform and branch free.  The autocorrelation is blocked the same way (4 lags per lane).
+// The clip level (median of the non-negative samples) comes from a 31-step bisection on the float bit
+// patterns held in registers (ballot + popcount per step): no sort, no LDS, no barrier.
+// Requires lag_min % 4 == 0, n_lags <= 256, ceil(L / (2 W)) <= 64 (so L <= 512).
+#define PITCH2_GUARD 256   // zeros behind f[] (>= lag_max + 4)
+
+template <int W>
+__global__ __launch_bounds__(64) void pitch_scores_kernel_v2(
+    const float* __restrict__ sig, BatchGeom bg, int32_t L, int32_t S, int32_t P, const float2* __restrict__ taps,
+    int32_t do_clip, int32_t lag_min, int32_t n_lags, float* __restrict__ scores) {
+    extern __shared__ __attribute__((aligned(16))) float smem_p[];
+    const int Lp = (L + W - 1) / W * W;                    // outputs are produced in chunks of W
+    float* cl0 = smem_p;                                   // [Lp zeros][Lp samples]: index i lives at cl0[Lp + i]
+    float2* h = reinterpret_cast<float2*>(cl0 + 2 * Lp);   // [Lp] taps, zero beyond L
+    float* f = reinterpret_cast<float*>(h + Lp);           // [Lp + PITCH2_GUARD]
+    (void)P;
+    const int lane = threadIdx.x;
+    const int64_t g = blockIdx.x;
+    int32_t utt;
+    int64_t t, s0, nsamp;
+    dsp_locate(bg, g, utt, t, s0, nsamp);
+    const int64_t first = t * (int64_t)S;
+    float* cl = cl0 + Lp;
+    // frame samples: lane owns elements lane + 64 r (r < 8, L <= 512); order statistics are found on
+    // the bit patterns (non-negative floats order like unsigned integers), everything else is 0xffffffff
+    float xr[8];
+    uint32_t kb[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int i = lane + 64 * r;
+        float x = 0.f;
+        const bool in = i < L;
+        if (in && first + i < nsamp) x = sig[s0 + first + i];
+        xr[r] = x;
+        const bool nn = in && x >= 0.f;
+        kb[r] = nn ? __float_as_uint(x + 0.f) : 0xffffffffu;        // x + 0 turns -0 into +0
+    }
+    for (int i = lane; i < Lp; i += 64) {
+        cl0[i] = 0.f;                                      // guard band: samples before the frame
+        if (i >= L) cl[i] = 0.f;
+        h[i] = i < L ? taps[i] : make_float2(0.f, 0.f);
+    }
+    for (int i = lane; i < Lp + PITCH2_GUARD; i += 64) f[i] = 0.f;
+    float med = 0.f;
+    if (do_clip) {
+        // wave-wide count of keys below a candidate: one v_cmp per register, popcount of the masks
+        auto count_below = [&](uint32_t cand) {
+            int c = 0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) c += __popcll(__ballot(kb[r] < cand));
+            return c;
+        };
+        int m = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) m += __popcll(__ballot(kb[r] != 0xffffffffu));
+        if (m > 0) {
+            // k-th smallest (0-based): the largest v with fewer than k + 1 keys below it, bit by bit
+            const int k1 = (m - 1) >> 1, k2 = m >> 1;
+            uint32_t v1 = 0;
+            for (int bit = 30; bit >= 0; --bit) {
+                const uint32_t cand = v1 | (1u << bit);
+                if (count_below(cand) <= k1) v1 = cand;
+            }
+            uint32_t v2 = v1;
+            if (k2 != k1 && count_below(v1 + 1) < k2 + 1) {
+                // the next distinct key above v1
+                uint32_t mn = 0xffffffffu;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) mn = (kb[r] > v1 && kb[r] < mn) ? kb[r] : mn;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const uint32_t other = (uint32_t)__shfl_xor((int)mn, o, 64);
+                    mn = other < mn ? other : mn;
+                }
+                v2 = mn;
+            }
+            med = 0.5f * (__uint_as_float(v1) + __uint_as_float(v2));     // numpy.median
+        } else {
+            med = __int_as_float(0x7fc00000);              // no non-negative sample: NaN clip level
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int i = lane + 64 * r;
+        if (i < L) {
+            const float x = xr[r];
+            cl[i] = do_clip ? (x > med ? x - med : (x < -med ? x + med : 0.f)) : x;
+        }
+    }
+    __syncthreads();
+    // ---- FIR: y[k] = sum_m h[m] c[k - m]; lane q owns outputs [W q, W q + W) and [Lp - W q - W, Lp - W q) ----
+    const int nchunk = (Lp / W + 1) / 2;
+    if (lane < nchunk) {
+        const int kl = W * lane, kh = Lp - W * (lane + 1);
+        float wl[W], wh[W];                                // ring: the sample at position p sits in slot p % W
+        float alr[W], ali[W], ahr[W], ahi[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            wl[e] = cl[kl + e];
+            wh[e] = cl[kh + e];
+            alr[e] = ali[e] = ahr[e] = ahi[e] = 0.f;
+        }
+        for (int m0 = 0; m0 < Lp; m0 += W) {
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                const int m = m0 + j;
+                if (m > 0) {                               // position k0 - m enters slot (-m) % W == (W - j) % W
+                    wl[(W - j) % W] = cl[kl - m];
+                    wh[(W - j) % W] = cl[kh - m];
+                }
+                const float2 hm = h[m];
+#pragma unroll
+                for (int e = 0; e < W; ++e) {
+                    const float vl = wl[(e - j + W) % W], vh = wh[(e - j + W) % W];
+                    alr[e] = fmaf(hm.x, vl, alr[e]); ali[e] = fmaf(hm.y, vl, ali[e]);
+                    ahr[e] = fmaf(hm.x, vh, ahr[e]); ahi[e] = fmaf(hm.y, vh, ahi[e]);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            if (kl + e < L) f[kl + e] = sqrtf(fmaf(alr[e], alr[e], ali[e] * ali[e]));
+            if (kh + e < L) f[kh + e] = sqrtf(fmaf(ahr[e], ahr[e], ahi[e] * ahi[e]));
+        }
+    }
+    __syncthreads();
+    // ---- autocorrelation: lane q owns lags lag_min + 4 q .. + 3; f is zero beyond L ----
+    const int nq = (n_lags + 3) / 4;
+    for (int q = lane; q < nq; q += 64) {
+        const int n0 = lag_min + 4 * q;                    // multiple of 4
+        float w[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 3; ++e) w[e] = f[n0 + e];      // positions n0 .. n0 + 2 in slots 0..2
+        for (int i0 = 0; i0 < L; i0 += 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + j;                      // window positions i + n0 .. i + n0 + 3
+                w[(j + 3) % 4] = f[i + n0 + 3];
+                const float a = i < L ? f[i] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(a, w[(j + e) % 4], acc[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = n0 + e;
+            if (4 * q + e < n_lags) {
+                float v;
+                if (n == 0 || n < L) v = acc[e] / (float)(L - n);
+                else v = __int_as_float(0x7fc00000);
+                scores[g * n_lags + 4 * q + e] = v;
+            }
+        }
+    }
+}

@@ -11,6 +11,7 @@ import torch
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=256)
+    ap.add_argument('--no-clip', action='store_true', help='skip the centre clipping (median sort)')
     args = ap.parse_args()
     from features import _native as nat
     from features import pitch as gp
@@ -30,7 +31,7 @@ def main():
 
     def run():
         nat.check(lib.dsp_pitch_scores_batch(x.data_ptr(), d_so.data_ptr(), d_fo.data_ptr(), args.batch, int(fo[-1]), 0,
-                                             L, S, taps.ptr, 1, 20, 200, out.data_ptr(), st))
+                                             L, S, taps.ptr, 0 if args.no_clip else 1, 20, 200, out.data_ptr(), st))
     for _ in range(3):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
