@@ -163,6 +163,16 @@ def test_pitch_scores_batch_and_tracks_vs_oracle():
     so = np.concatenate(([0], np.cumsum([len(c) for c in clips]))).astype(np.int64)
     scores, fo = gp.frame_scores_batch(np.concatenate(clips), so, 300, 100)
     assert scores.shape == (fo[-1], 180)
+    # the one-workgroup-per-frame kernel (bitonic sort, scalar loops) is an independent implementation
+    from features import _native as nat
+    for L in (300, 512):
+        try:
+            nat.check(nat.load().dsp_debug_force_generic(1))
+            slow, _ = gp.frame_scores_batch(np.concatenate(clips), so, L, 100)
+        finally:
+            nat.check(nat.load().dsp_debug_force_generic(0))
+        fast, _ = gp.frame_scores_batch(np.concatenate(clips), so, L, 100)
+        assert normwise(fast, slow) <= 1e-5, (L, normwise(fast, slow))
     for b, c in enumerate(clips):
         frames = dsp_oracle.to_frames(c, 10000, 0.03, 0.01)
         assert fo[b + 1] - fo[b] == len(frames)
