@@ -194,3 +194,22 @@ def test_pitch_scores_batch_and_tracks_vs_oracle():
         assert len(got) == len(ref)
         same = np.isclose(got, ref, rtol=1e-9, atol=0)
         assert same.mean() >= 0.98, (rate, same.mean())     # an arg-max over fp32 scores may flip on a near tie
+
+
+def test_long_utterance_takes_the_serial_rule_path():
+    """Utterances longer than 2048 VAD frames (20.5 s) do not fit the rule kernel's LDS copy and are
+    scanned straight from HBM by one lane: same endpoints as the oracle, mixed in a batch with short
+    clips that take the LDS path."""
+    from features.batch import EndpointPlan
+    from oracle import dsp_oracle
+    rng = np.random.default_rng(5)
+    clips = []
+    for n, b0, blen in ((16000 * 31, 16000 * 7, 16000 * 9), (16000, 3000, 9000), (16000 * 25, 16000 * 20, 16000 * 3)):
+        x = rng.normal(0, 30, n)
+        t = np.arange(blen) / 16000.0
+        x[b0:b0 + blen] += 8000 * np.sin(2 * np.pi * 180 * t) * np.hanning(blen)
+        clips.append(np.clip(np.round(x), -32768, 32767).astype(np.int16))
+    so = np.concatenate(([0], np.cumsum([len(c) for c in clips]))).astype(np.int64)
+    got = EndpointPlan(16000, 0.03, 0.01).detect_batch(np.concatenate(clips), sample_offsets=so)
+    for b, c in enumerate(clips):
+        assert tuple(got[b]) == dsp_oracle.basic_endpoint_detection(c, 16000), b
