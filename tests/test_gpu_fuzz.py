@@ -213,3 +213,16 @@ def test_long_utterance_takes_the_serial_rule_path():
     got = EndpointPlan(16000, 0.03, 0.01).detect_batch(np.concatenate(clips), sample_offsets=so)
     for b, c in enumerate(clips):
         assert tuple(got[b]) == dsp_oracle.basic_endpoint_detection(c, 16000), b
+
+
+@pytest.mark.parametrize('T,D,N', [(500, 64, 9), (1, 5, 4), (3, 13, 3), (1000, 200, 2), (129, 13, 1)])
+def test_delta_shapes_beyond_the_tiled_kernel(T, D, N):
+    """base.delta for widths / window sizes whose tile does not fit the LDS budget (per-element
+    kernel), for T < N (everything is edge padding) and across the 128-frame tile seam."""
+    import features
+    from oracle import dsp_oracle
+    x = np.random.default_rng(T + D).standard_normal((T, D))
+    got = features.delta(x, N)
+    ref = dsp_oracle.delta(x.astype(np.float32).astype(np.float64), N)
+    assert got.shape == ref.shape
+    assert np.max(np.abs(got - ref)) <= 1e-5 * max(1.0, np.max(np.abs(ref)))
