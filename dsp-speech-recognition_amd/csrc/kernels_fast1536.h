@@ -31,7 +31,7 @@
 #define F1536_MAX_NI 4
 #define F1536_SLOTS 64         // mel work items per wave (one per lane)
 #define F1536_PIECES 8         // a filter is cut into at most this many slots
-#define F1536_PART_STRIDE 72   // 64 partial sums + the always-zero slot + padding, per frame
+#define F1536_PART_STRIDE F1536_PS_STRIDE   // partial sums overwrite the head of each frame's (dead) spectrum row
 #ifndef F1536_WAVES
 #define F1536_WAVES 8
 #endif
@@ -389,6 +389,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mfcc1536_kernel(F1536Params P, 
                     a1[g] = fmaf(w1.w, q1[g].w, a1[g]);
                 }
             }
+            F512_FENCE();
 #pragma unroll
             for (int g = 0; g < 4; ++g) part[g * F1536_PART_STRIDE + lane] = a0[g] + a1[g];
             if (lane < 4) part[lane * F1536_PART_STRIDE + F1536_SLOTS] = 0.f;   // the "no piece" slot
@@ -530,8 +531,10 @@ static inline int fast1536_plan_init(dsp_plan* p, const dsp_plan_desc* d, const 
     size_t wave_floats = 4 * F1536_PS_STRIDE;
     if ((size_t)4 * (span_vec + 1) > wave_floats) wave_floats = (size_t)4 * (span_vec + 1);
     if ((size_t)4 * F1536_XSTRIDE > wave_floats) wave_floats = 4 * F1536_XSTRIDE;
-    const size_t off_part = pad64(wave_floats);       // partial sums live behind the spectrum rows
-    wave_floats = pad64(off_part + 4 * F1536_PART_STRIDE);
+    // partial sums reuse the first 65 floats of each spectrum row: a wave's LDS operations execute in
+    // order, so every lane's mel reads are done before the first partial sum lands
+    const size_t off_part = 0;
+    wave_floats = pad64(wave_floats);
     if (!ok || (total + F1536_WAVES * wave_floats) * 4 > 160 * 1024) {  // does not fit one CU's LDS: generic kernel
         delete fp;
         return DSP_OK;
