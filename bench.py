@@ -39,6 +39,25 @@ BYTES_PER_FRAME_ALL = 4.0 * N / T + 4.0 * 39         # 802.5: SURVEY 8d, MFCC+de
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+# Second roof (fp32 vector issue): wave instructions the fused MFCC kernel executes per frame x 64 lanes,
+# from the rocprofv3 SQ_INSTS_VALU pass in profiles/ (DESIGN.md section 7), against 256 CUs x 4 SIMDs x
+# 32 lanes x 2.4 GHz = 78.6 T lane-ops/s.
+VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9
+
+
+def compute_roof(kernel_ms):
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r2_instr.json')) as fh:
+            ij = json.load(fh)
+        lane_ops = float(ij['valu_lane_ops_per_frame'])
+        src = 'profiles/r2_instr.json'
+    except (OSError, ValueError, KeyError):
+        lane_ops, src = 1735.0 * 64 / 8, 'profiles/r1_pmc_summary.txt (1735 VALU wave-instructions per 8 frames)'
+    ach = lane_ops * B * T / (kernel_ms * 1e-3)
+    return {'bound': 'valu', 'achieved': ach / 1e12, 'peak': VALU_PEAK_LANEOPS / 1e12, 'unit': 'T lane-ops/s',
+            'frac': ach / VALU_PEAK_LANEOPS, 'lane_ops_per_frame': lane_ops, 'source': src}
+
+
 def synth_batch(seed):
     """Class-A throughput signal of SURVEY 8d: 0.25 * N(0,1), fp32."""
     rng = np.random.default_rng(1_000_003 * 17 + seed)
@@ -170,6 +189,35 @@ def other_paths(dev):
     return out
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N rank processes ourselves.  The parent
+    makes NO GPU call (torch.cuda.device_count() does not initialise the runtime on this image); the
+    ranks are fresh children, never an exec of a process that has touched the GPU."""
+    import subprocess
+    import torch
+    n_dev = torch.cuda.device_count()
+    if args.gpus > n_dev:
+        sys.stderr.write(f'bench.py: --gpus {args.gpus} requested but only {n_dev} GPU(s) are visible on this '
+                         f'node; refusing to report an {args.gpus}-GPU number from fewer devices\n')
+        raise SystemExit(2)
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rcs = [p.wait() for p in procs]
+    raise SystemExit(max(abs(rc) for rc in rcs))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -177,19 +225,35 @@ def main():
     ap.add_argument('--warmup', type=int, default=200)
     ap.add_argument('--buffers', type=int, default=8, help='distinct input batches rotated over (x65.5 MB)')
     ap.add_argument('--streams', type=int, default=3, help='HIP streams the independent steps alternate over')
+    ap.add_argument('--min-time', type=float, default=0.6,
+                    help='the K-step timed block is repeated until this many seconds have been timed')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gather', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the NFFT=1536 / configs[3] side timings')
     args = ap.parse_args()
+    if args.gpus < 1 or args.steps < 1:
+        raise SystemExit('bench.py: --gpus and --steps must be >= 1')
+
+    if 'WORLD_SIZE' not in os.environ:
+        if args.gpus > 1:
+            launch_ranks(args)          # does not return
+        rank = local_rank = 0
+        world = 1
+    else:
+        rank = int(os.environ.get('RANK', '0'))
+        local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        world = int(os.environ['WORLD_SIZE'])
+        if world != args.gpus:
+            raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
 
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f'bench.py: rank {rank} has no GPU (LOCAL_RANK {local_rank}, '
+                         f'{torch.cuda.device_count()} visible)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
@@ -212,13 +276,15 @@ def main():
     stream = torch.cuda.current_stream(dev)
     sp = stream.cuda_stream
     # Steps are independent (own input batch, own output buffer), so consecutive steps alternate over
-    # `--streams` HIP streams: the tail of one launch overlaps the head of the next.
+    # `--streams` HIP streams: the tail of one launch overlaps the head of the next.  Every stream
+    # owns two output buffers, so no buffer is ever touched from two streams.
     streams = [torch.cuda.Stream(dev) for _ in range(args.streams)] if args.streams > 1 else [stream]
-    outs = [torch.empty((B * T, D), dtype=torch.float32, device=dev) for _ in range(max(4, len(streams)))]
+    ns = len(streams)
+    outs = [[torch.empty((B * T, D), dtype=torch.float32, device=dev) for _ in range(2)] for _ in range(ns)]
 
     def step(i):
-        k = i % len(streams)
-        plan.run_raw(waves[i % len(waves)].data_ptr(), nat.WAVE_F32, layout, outs[i % len(outs)].data_ptr(),
+        k = i % ns
+        plan.run_raw(waves[i % len(waves)].data_ptr(), nat.WAVE_F32, layout, outs[k][(i // ns) & 1].data_ptr(),
                      DELTA_N, streams[k].cuda_stream)
 
     def sync_all():
@@ -226,6 +292,32 @@ def main():
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize(dev)
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in streams]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in streams]
+
+    def timed_block(i0):
+        """EXACTLY args.steps steps between two barrier + synchronize pairs; returns (host wall seconds,
+        device-side span in ms measured with HIP events on every launch stream)."""
+        sync_all()
+        for e, s_ in zip(ev0, streams):
+            e.record(s_)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i0 + i)
+        for e, s_ in zip(ev1, streams):
+            e.record(s_)
+        sync_all()
+        dt = time.perf_counter() - t0
+        span = max(a.elapsed_time(b) for a, b in zip(ev0, ev1))
+        return max_over_ranks(dt), span
 
     # Untimed pre-warm (clock ramp, TLBs, code objects): a fixed 0.3 s of steps before the W warmup
     # steps -- the first few hundred steps after an idle period run ~13 % slower on this device.
@@ -238,36 +330,38 @@ def main():
         torch.cuda.synchronize(dev)
     for i in range(args.warmup):
         step(i)
-    sync_all()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    sync_all()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    # The K-step block is timed R times (R from the first block, identical on all ranks) so that the
+    # timed region covers >= --min-time seconds even when K is small; the line reports the median.
+    blocks = [timed_block(0)]
+    n_blocks = int(min(1000, max(3, np.ceil(args.min_time / max(blocks[0][0], 1e-6)))))
+    for r in range(1, n_blocks):
+        blocks.append(timed_block(r * args.steps))
+    walls = np.array([b[0] for b in blocks])
+    spans = np.array([b[1] for b in blocks])
+    dt = float(np.median(walls))
 
     # --- dominant kernel (fused MFCC) timed alone with events on the launch stream, same rotation ---
     lib = nat.load()
 
     def mfcc_only(i):
         nat.check(lib.dsp_features_batch(plan.plan.handle, waves[i % len(waves)].data_ptr(), nat.WAVE_F32, None,
-                                         None, B, B * T, N, nat.OUT_MFCC, outs[i % len(outs)].data_ptr(), D,
+                                         None, B, B * T, N, nat.OUT_MFCC, outs[0][i & 1].data_ptr(), D,
                                          None, sp))
 
-    ksteps = max(10, min(args.steps, 200))
-    for i in range(5):
-        mfcc_only(i)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(dev)
-    ev0.record(stream)
-    for i in range(ksteps):
-        mfcc_only(i)
-    ev1.record(stream)
-    torch.cuda.synchronize(dev)
-    kernel_ms = ev0.elapsed_time(ev1) / ksteps
+    ksteps = 200
+    kev0, kev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ktimes = []
+    for rep in range(5):
+        for i in range(5):
+            mfcc_only(i)
+        torch.cuda.synchronize(dev)
+        kev0.record(stream)
+        for i in range(ksteps):
+            mfcc_only(i)
+        kev1.record(stream)
+        torch.cuda.synchronize(dev)
+        ktimes.append(kev0.elapsed_time(kev1) / ksteps)
+    kernel_ms = float(np.median(ktimes))
 
     # --- parity guard on batch 0 (outside the timed region): HIP path vs the CPU oracle ---
     parity = None
@@ -275,7 +369,7 @@ def main():
         from oracle import dsp_oracle
         step(0)
         torch.cuda.synchronize(dev)
-        got = outs[0].cpu().numpy().reshape(B, T, D)
+        got = outs[0][0].cpu().numpy().reshape(B, T, D)
         parity = 0.0
         for b in (0, 1, B // 2, B - 1):
             ref = dsp_oracle.mfcc_delta(host0[b].astype(np.float64), delta_n=DELTA_N, winfunc=np.hamming, **CFG)
@@ -286,26 +380,38 @@ def main():
     if world > 1 and not args.no_gather:
         gbuf = torch.empty((world * B * T, D), dtype=torch.float32, device=dev)
         for _ in range(2):
-            dist.all_gather_into_tensor(gbuf, outs[0])
+            dist.all_gather_into_tensor(gbuf, outs[0][0])
         sync_all()
         g0 = time.perf_counter()
         reps = 5
         for _ in range(reps):
-            dist.all_gather_into_tensor(gbuf, outs[0])
+            dist.all_gather_into_tensor(gbuf, outs[0][0])
         sync_all()
-        gms = (time.perf_counter() - g0) / reps * 1e3
+        gms = max_over_ranks((time.perf_counter() - g0) / reps * 1e3)
         gather = {'collective': 'rccl all_gather_into_tensor', 'bytes_per_rank': B * T * D * 4, 'ms': gms,
                   'algbw_GBps': world * B * T * D * 4 / gms / 1e6}
+    per_rank_ms = None
+    if world > 1:
+        mine = torch.tensor([float(np.median([b[1] for b in blocks])) / args.steps], dtype=torch.float64, device=dev)
+        allr = torch.zeros(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allr, mine)
+        per_rank_ms = [float(x) for x in allr.cpu()]
 
     # HBM traffic per launch measured with rocprofv3 PMC passes (cannot be collected inside this process)
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r1_traffic.json')) as fh:
-            tj = json.load(fh)
-        if tj.get('frames_per_launch') == B * T:
-            traffic = tj['traffic_bytes_per_launch']
-    except (OSError, ValueError, KeyError):
-        traffic = None
+    traffic, step_traffic, traffic_source = None, None, None
+    for name in ('r2_traffic.json', 'r1_traffic.json'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', name)) as fh:
+                tj = json.load(fh)
+            if tj.get('frames_per_launch') == B * T:
+                traffic = tj['traffic_bytes_per_launch']
+                step_traffic = tj.get('step_traffic_bytes')
+                traffic_source = (f'profiles/{name}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this '
+                                  f'workload (FETCH doubled per the gfx950 guide); a constant read from that file, '
+                                  f'not measured in this run')
+                break
+        except (OSError, ValueError, KeyError):
+            continue
 
     frames_total = float(world) * B * T * args.steps
     value = frames_total / dt
@@ -315,21 +421,35 @@ def main():
         'value': value, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'timing': {'blocks_of_K_steps': int(n_blocks), 'timed_seconds': float(walls.sum()),
+                   'ms_per_step_median': dt / args.steps * 1e3,
+                   'ms_per_step_min': float(walls.min()) / args.steps * 1e3,
+                   'ms_per_step_max': float(walls.max()) / args.steps * 1e3,
+                   'note': 'every block = exactly K steps between barrier+synchronize pairs, max over ranks; '
+                           'value uses the median block'},
         'config': {'workload': 'configs[1]: batch of 1024 synthetic 1 s 16 kHz utterances -> MFCC+delta+delta2 '
                                '[1024*99, 39] per step per GPU', 'utterances_per_step_per_gpu': B,
                    'frames_per_utterance': T, 'delta_n': DELTA_N, 'input_buffers_rotated': len(waves),
-                   'hip_streams': len(streams),
+                   'hip_streams': ns,
                    'sharding': f'{world} ranks x independent batches, no data-path collective'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
+                     'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic, 'traffic_source': traffic_source,
+                     'step_traffic': step_traffic,
                      'frac_of_measured_copy_ceiling': achieved / 6290.0,   # MI355X_MICROARCH.md: 6.29 TB/s copy
                      'algorithmic_bytes_per_launch': BYTES_PER_FRAME_MFCC * B * T,
                      'kernel': 'fused MFCC kernel (dsp_features_batch, DSP_OUT_MFCC)',
-                     'kernel_ms': kernel_ms, 'bytes_per_frame': BYTES_PER_FRAME_MFCC,
-                     'frames_per_launch': B * T,
-                     'whole_step_GBps': BYTES_PER_FRAME_ALL * value / world / 1e9},
+                     'kernel_ms': kernel_ms, 'kernel_ms_note': 'one launch stream, back to back, HIP events',
+                     'kernel_ms_overlapped': float(np.median(spans)) / args.steps,
+                     'kernel_ms_overlapped_note': 'device-side span of a timed block (HIP events on every launch '
+                                                  'stream, max over streams) / K: MFCC + delta kernels of one step '
+                                                  'under the stream overlap of the timed region; <= ms_per_step',
+                     'bytes_per_frame': BYTES_PER_FRAME_MFCC, 'frames_per_launch': B * T,
+                     'whole_step_GBps': BYTES_PER_FRAME_ALL * value / world / 1e9,
+                     'compute': compute_roof(kernel_ms)},
         'parity_normwise_vs_oracle': parity,
     }
+    if per_rank_ms is not None:
+        res['per_rank_ms_per_step'] = per_rank_ms
     if gather is not None:
         res['gather'] = gather
     if rank == 0 and world == 1 and not args.no_extras:
@@ -337,7 +457,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline()
     if rank == 0:
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -194,8 +194,20 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
     float* wbuf = smem + P.tab_floats + wid * F512_WAVE_FLOATS;
     const int total_groups = RAGGED ? P.group_off[bg.n_utt] : (int)P.total_groups;
     const int gstride = (int)gridDim.x * WAVES;
+    // Full rounds: wave w of block b takes group r * gstride + 8 b + w (the eight waves of a workgroup
+    // hold eight consecutive groups, whose overlapping samples are re-read through one CU's L1 / L2).
+    // The last, partial round is dealt wave-major instead (group base + b + gridDim * w): its groups
+    // go to wave 0 of every workgroup first, so no SIMD carries more than one group above the average.
+    const int nfull = total_groups / gstride;
 
-    for (int G = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WAVES + wid); G < total_groups; G += gstride) {
+    for (int r = 0; r <= nfull; ++r) {
+        int G;
+        if (r < nfull) {
+            G = __builtin_amdgcn_readfirstlane(r * gstride + (int)blockIdx.x * WAVES + wid);
+        } else {
+            G = __builtin_amdgcn_readfirstlane(nfull * gstride + (int)blockIdx.x + (int)gridDim.x * wid);
+            if (G >= total_groups) break;
+        }
         // Lane-derived addresses are recomputed every iteration on purpose: hoisted out of the loop
         // they would pin ~30 VGPRs for the whole kernel (the opaque asm stops the hoisting).
         int lane = tid & 63;
@@ -678,9 +690,14 @@ static int fast512_launch_k(const F512Params& P, const void* d_wave, const Batch
     // balanced persistent grid: every wave runs the same number of groups (no ragged last round)
     const int64_t cap = 256 * (16 / F512_WAVES);  // 256 CUs x resident workgroups (<= 16 waves per CU)
     int64_t blocks = (groups_bound + F512_WAVES - 1) / F512_WAVES;
+    static const int grid_mode = [] { const char* e = getenv("DSP_F512_GRID"); return e ? atoi(e) : 1; }();
     if (blocks > cap) {
-        const int64_t rounds = (blocks + cap - 1) / cap;
-        blocks = (blocks + rounds - 1) / rounds;
+        if (grid_mode == 0) {   // every wave the same number of groups (fewer, fuller workgroups)
+            const int64_t rounds = (blocks + cap - 1) / cap;
+            blocks = (blocks + rounds - 1) / rounds;
+        } else {
+            blocks = cap;       // every CU fully occupied; the partial last round is dealt wave-major
+        }
     }
     auto k = mfcc512_kernel<NROWS, NI, NC, NSTAGE, DTYPE, F512_WAVES, RAGGED>;
     static size_t granted[DSP_MAX_DEVICES] = {};  // dynamic-LDS limit already raised, per device

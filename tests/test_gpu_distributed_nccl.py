@@ -1,0 +1,113 @@
+"""N>1 path on the GPU: `nccl` (= RCCL) ranks, one per visible device (1 on a single-GPU lease, capped
+at 6), shard a ragged batch with features.distributed, compute their share with the HIP kernels on
+device tensors and gather -- the result must equal the single-process result row for row.  Also
+checks the rank launcher of bench.py."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from test_distributed_gloo import CFG, _batch, _free_port
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, 'dsp-speech-recognition_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    try:
+        torch.cuda.set_device(rank)
+        dev = torch.device('cuda', rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    except Exception as e:
+        q.put((rank, None, None, None, 'init: ' + repr(e)))
+        return
+    try:
+        from features import _native as nat
+        from features import distributed as D
+        from features.batch import FeaturePlan
+        nat.check(nat.load().dsp_set_device(rank))
+        plan = FeaturePlan(winfunc=np.hamming, **CFG)
+        waves, so = _batch()
+        d_waves = torch.from_numpy(waves).to(dev)
+
+        def compute(local_waves, local_so):
+            return plan.mfcc_batch(local_waves, local_so, delta_n=2)
+
+        rows, counts = D.extract_sharded(compute, d_waves, so)
+        assert rows.is_cuda
+        full, _ = compute(d_waves, so)                       # this rank alone, whole batch
+        lo, hi, local_so = D.local_slice(so, world, rank)
+        local_feats, _ = compute(d_waves[so[lo]:so[hi]], local_so)
+        only0, _ = D.gather_features(local_feats, dst=0)
+        torch.cuda.synchronize(dev)
+        q.put((rank, rows.cpu().numpy(), counts, full.cpu().numpy(),
+               None if only0 is None else only0.cpu().numpy(), None))
+    except Exception as e:  # surface the failure instead of letting the parent time out
+        q.put((rank, None, None, None, None, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_nccl_shard_and_gather_on_device_tensors():
+    import torch
+    import torch.multiprocessing as mp
+    world = min(torch.cuda.device_count(), 6)
+    assert world >= 1, 'no GPU visible'
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[-1] is None, r[-1]
+    for rank, rows, counts, full, only0, _ in res:
+        assert sum(counts) == full.shape[0] and len(counts) == world
+        # sharding never changes a row: ragged batches run the same kernel instantiation whatever the split
+        assert np.array_equal(rows, full), f'rank {rank}: gathered rows differ from the single-process result'
+        if rank == 0:
+            assert np.array_equal(only0, full)
+        else:
+            assert only0 is None
+
+
+@pytest.mark.gpu
+def test_bench_refuses_more_ranks_than_devices():
+    import torch
+    n = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n + 1), '--steps', '5',
+                        '--warmup', '1'], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert 'GPU(s) are visible' in r.stderr and not r.stdout.strip()
+
+
+def test_bench_gpus_flag_is_honoured_without_a_gpu():
+    """On the CPU container there are 0 devices: `--gpus 2` must fail loudly, never report n_gpus=1."""
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], capture_output=True,
+                       text=True, timeout=300, env=env)
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('two GPUs visible: the launcher would really run')
+    assert r.returncode != 0 and 'requested but only' in r.stderr
+
+
+def test_bench_rejects_launcher_mismatch():
+    env = dict(os.environ, WORLD_SIZE='4', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert r.returncode != 0 and 'WORLD_SIZE=4' in (r.stderr + r.stdout)

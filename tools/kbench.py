@@ -24,6 +24,7 @@ def main():
     ap.add_argument('--batch', type=int, default=1024)
     ap.add_argument('--nfilt', type=int, default=40)
     ap.add_argument('--streams', type=int, default=1)
+    ap.add_argument('--check', default='', help='npy file: written if absent, else compared with the MFCC+delta output of batch 0')
     args = ap.parse_args()
     from features import _native as nat
     from features.batch import FeaturePlan
@@ -50,6 +51,16 @@ def main():
         k = i % len(streams)
         plan.run_raw(waves[i % 8].data_ptr(), nat.WAVE_F32, layout, outs[k].data_ptr(), 2, streams[k].cuda_stream)
 
+    if args.check:
+        full(0)
+        torch.cuda.synchronize()
+        got = outs[0].cpu().numpy()
+        if os.path.exists(args.check):
+            ref = np.load(args.check)
+            err = float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
+            print(f'check vs {os.path.basename(args.check)}: normwise {err:.2e}' + ('  <-- MISMATCH' if not err <= 2e-5 else ''))
+        else:
+            np.save(args.check, got)
     res = {}
     for name, fn in (('mfcc', mfcc_only), ('mfcc+delta', full)):
         for i in range(10):
