@@ -70,6 +70,37 @@ __device__ __forceinline__ float frame_allreduce(float v) {
 
 #define F512_FENCE() asm volatile("" ::: "memory")
 
+// Diagnostic build (-DF512_STAMPS, see tools/kbench.py): every wave accumulates the shader-clock span of
+// each phase of its groups in registers and adds them to a per-wave slot at exit; phases are pinned with
+// empty volatile asms so the compiler cannot move arithmetic across a stamp.  Never in the product library.
+#ifdef F512_STAMPS
+#define F512_NSTAMP 16
+__device__ unsigned int f512_stamp_sum[F512_NSTAMP * 8192];   // [wave slot][phase]
+__device__ __forceinline__ unsigned int f512_clock() {
+    unsigned long long t;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return (unsigned int)t;
+}
+template <typename T, int N>
+__device__ __forceinline__ void f512_pin(T (&a)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if constexpr (sizeof(T) == 8) asm volatile("" : "+v"(a[i].x), "+v"(a[i].y));
+        else asm volatile("" : "+v"(a[i]));
+    }
+}
+#define F512_STAMP(i)                                     \
+    do {                                                  \
+        const unsigned int now_ = f512_clock();           \
+        stamp_acc_[i] += now_ - stamp_prev_;              \
+        stamp_prev_ = f512_clock();                       \
+    } while (0)
+#define F512_PIN(a) f512_pin(a)
+#else
+#define F512_STAMP(i) do {} while (0)
+#define F512_PIN(a) do {} while (0)
+#endif
+
 typedef float f512_v2 __attribute__((ext_vector_type(2)));
 // Pass-1 reads are plain ds_read_b64 (2 LDS cycles per wave, 64-bank addressing) issued from inline
 // asm: hipcc would pair neighbouring b64 reads into ds_read2_b64, which costs 8 cycles and uses
@@ -182,6 +213,10 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
     extern __shared__ __attribute__((aligned(256))) float smem_f[];
     float* const smem = smem_f;
     const int tid = threadIdx.x;
+#ifdef F512_STAMPS
+    const unsigned int stamp_entry_ = f512_clock();
+    const unsigned int stamp_rt0_ = (unsigned int)__builtin_amdgcn_s_memrealtime();
+#endif
     for (int i = tid * 4; i < P.tab_floats; i += 64 * WAVES * 4)
         *reinterpret_cast<float4*>(smem + i) = *reinterpret_cast<const float4*>(P.tables + i);
     __syncthreads();
@@ -199,6 +234,11 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
     // The last, partial round is dealt wave-major instead (group base + b + gridDim * w): its groups
     // go to wave 0 of every workgroup first, so no SIMD carries more than one group above the average.
     const int nfull = total_groups / gstride;
+#ifdef F512_STAMPS
+    unsigned int stamp_acc_[F512_NSTAMP] = {};
+    unsigned int stamp_prev_ = f512_clock();
+    const unsigned int stamp_loop0_ = stamp_prev_;
+#endif
 
     for (int r = 0; r <= nfull; ++r) {
         int G;
@@ -210,6 +250,7 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         }
         // Lane-derived addresses are recomputed every iteration on purpose: hoisted out of the loop
         // they would pin ~30 VGPRs for the whole kernel (the opaque asm stops the hoisting).
+        F512_STAMP(0);
         int lane = tid & 63;
         asm volatile("" : "+v"(lane));
         const int f = lane >> 3, c = lane & 7;
@@ -273,6 +314,7 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
             }
         }
         F512_FENCE();
+        F512_STAMP(1);
 
         // ---- pass 1: window, complex FFT32 over n1 of (column 2c) + i (column 2c+1) ----
         cpx z[32];
@@ -295,6 +337,9 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         }
         FFTReg<32>::template run<NROWS>(z);
         F512_FENCE();
+        F512_PIN(z);
+        F512_STAMP(2);
+        F512_PIN(z);
 
         // untangle the two real columns (rows k1 = 0..16, factor 2 kept) and twiddle by W512^(n2 k1)
         cpx ra[16], rb[16];  // index k1 = 1..15 used
@@ -309,6 +354,9 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         }
         const float qa = 2.f * z[0].x, qb = 2.f * z[0].y, pa = 2.f * z[16].x, pb = 2.f * z[16].y;
 
+        F512_PIN(ra); F512_PIN(rb);
+        F512_STAMP(3);
+        F512_PIN(ra); F512_PIN(rb);
         // ---- exchange round A: units 0..7 (unit 0 = packed rows 0/16, units 1..7 = rows 1..7) ----
         float* xb = wbuf + f * 256;
         cpx u0[16], u1[16];
@@ -347,9 +395,15 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
             F512_FENCE();
         }
 
+        F512_PIN(u0); F512_PIN(u1);
+        F512_STAMP(4);
+        F512_PIN(u0); F512_PIN(u1);
         // ---- pass 2: two complex FFT16 over n2 ----
         FFTReg<16>::run(u0);
         FFTReg<16>::run(u1);
+        F512_PIN(u0); F512_PIN(u1);
+        F512_STAMP(5);
+        F512_PIN(u0); F512_PIN(u1);
 
         // power spectrum |X|^2 / 512: rows carry a factor 2 -> 1/2048.  That power of two is applied
         // (exactly) to the mel weights at plan time and to the energy sum once, not to every bin.
@@ -407,6 +461,9 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         energy = S1 * frame_allreduce(energy);
         if (energy == 0.f) energy = DSP_EPS_F32;
 
+        F512_PIN(p0); F512_PIN(p1); F512_PIN(podd);
+        F512_STAMP(6);
+        F512_PIN(p0); F512_PIN(p1); F512_PIN(podd);
         // ---- power spectrum -> LDS row of this frame: two base registers, immediate offsets ----
         float* ps = wbuf + f * F512_PS_STRIDE;
         {
@@ -429,6 +486,7 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
             }
         }
         F512_FENCE();
+        F512_STAMP(7);
 
         // ---- sparse mel triangles, log.  Lane c owns filters c + 8 i; its weights sit in one LDS
         //      row, the spectrum bins of a filter are contiguous from a 16-byte aligned start, so both
@@ -461,6 +519,9 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
             }
         }
         F512_FENCE();
+        F512_PIN(lm);
+        F512_STAMP(8);
+        F512_PIN(lm);
 
         // ---- DCT-II * lifter partial sums over this lane's filters, all-reduce over the frame ----
         float cep[NC];
@@ -482,6 +543,9 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         for (int k = 0; k < NC; ++k) cep[k] = frame_allreduce(cep[k]);
         if (P.append_energy) cep[0] = __logf(energy);
 
+        F512_PIN(cep);
+        F512_STAMP(9);
+        F512_PIN(cep);
         // ---- store: lane c writes coefficients c and c + 8 of its frame ----
         float v0 = cep[0], v1 = NC > 8 ? cep[8] : 0.f;
 #pragma unroll
@@ -496,7 +560,18 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
             if (c + 8 < P.C) o[c + 8] = v1;
         }
         F512_FENCE();
+        F512_STAMP(10);
     }
+#ifdef F512_STAMPS
+    stamp_acc_[11] = f512_clock() - stamp_entry_;
+    stamp_acc_[12] = (unsigned int)__builtin_amdgcn_s_memrealtime() - stamp_rt0_;
+    stamp_acc_[13] = stamp_loop0_ - stamp_entry_;
+    stamp_acc_[14] = 1;
+    if ((tid & 63) == 0) {
+        const int slot = ((int)blockIdx.x * WAVES + wid) & 8191;
+        for (int i = 0; i < F512_NSTAMP; ++i) f512_stamp_sum[slot * F512_NSTAMP + i] += stamp_acc_[i];
+    }
+#endif
 }
 
 // Ragged batches: group_off[b] = sum_{i<b} ceil(T_i / 2^shift) (exclusive prefix, single block), then the

@@ -61,6 +61,27 @@ def main():
             print(f'check vs {os.path.basename(args.check)}: normwise {err:.2e}' + ('  <-- MISMATCH' if not err <= 2e-5 else ''))
         else:
             np.save(args.check, got)
+    import ctypes
+    raw = ctypes.CDLL(nat.LIB_PATH)
+    if hasattr(raw, 'dsp_debug_read_stamps'):           # diagnostic build: per-phase cycle sums
+        buf = (ctypes.c_ulonglong * 16)()
+        for i in range(20):
+            mfcc_only(i)
+        raw.dsp_debug_read_stamps(buf, 16)
+        for i in range(100):
+            mfcc_only(i)
+        raw.dsp_debug_read_stamps(buf, 16)
+        groups = 100 * B * ((T + 7) // 8)
+        names = ['loop/locate', 'hbm load + stage', 'pass1 reads+window+FFT32', 'untangle+twiddle', 'exchange',
+                 '2 x FFT16', 'power+packed unit+energy', 'ps write', 'mel+log', 'DCT+allreduce', 'store']
+        tot = sum(buf[i] for i in range(11))
+        for i, nm in enumerate(names):
+            print(f'  phase {i:2d} {nm:28s} {buf[i] / groups:8.0f} cycles/group  {100.0 * buf[i] / tot:5.1f} %')
+        print(f'  total {tot / groups:8.0f} cycles per group (wave lifetime)')
+        if buf[14]:
+            nw = buf[14]
+            print(f'  per wave: lifetime {buf[11] / nw:9.0f} cycles, prologue {buf[13] / nw:7.0f} cycles, in-loop '
+                  f'{tot / nw:9.0f}; shader clock {buf[11] / max(buf[12], 1) * 0.1:5.2f} GHz; waves {nw / 100:.0f} per launch')
     res = {}
     for name, fn in (('mfcc', mfcc_only), ('mfcc+delta', full)):
         for i in range(10):
