@@ -2,6 +2,4 @@
 mkdir -p gpurun_out
 python -m pytest tests -m gpu -x -q > gpurun_out/r2_job4_tests.txt 2>&1; echo "tests rc=$?" >> gpurun_out/r2_job4_tests.txt
 bash tools/kbench_variants.sh --reps 300 --rounds 5 > gpurun_out/r2_job4_variants.txt 2>&1
-echo "--- new, DSP_F512_NOGAP=1" >> gpurun_out/r2_job4_variants.txt
-DSP_F512_NOGAP=1 DSP_FRONTEND_LIB=$PWD/dsp-speech-recognition_amd/lib/variants/new.so python tools/kbench.py --reps 300 --rounds 5 2>&1 | grep -v amdgpu.ids >> gpurun_out/r2_job4_variants.txt
 tail -5 gpurun_out/r2_job4_tests.txt; cat gpurun_out/r2_job4_variants.txt
