@@ -113,7 +113,7 @@ def other_paths(dev):
     variable-length int16 utterances.  Reported for the record next to the headline number."""
     import torch
     from features import _native as nat
-    from features.batch import EndpointPlan, FeaturePlan, _BatchLayout
+    from features.batch import FeaturePlan
     lib = nat.load()
     st = torch.cuda.current_stream(dev).cuda_stream
 
@@ -143,7 +143,10 @@ def other_paths(dev):
     out['nfft1536_mfcc'] = {'workload': '512 x 1 s at 48 kHz, 30 ms / 10 ms, nfft=1536, 26 mel -> 13 cep',
                             'frames': lay2.total_frames, 'us_per_launch': us,
                             'frames_per_s': lay2.total_frames / us * 1e6, 'algorithmic_GBps': byt / us / 1e3}
-    # --- configs[3]: VAD features -> endpoint rule -> trim + unit variance -> ragged MFCC+delta+delta2 ---
+    # --- configs[3]: VAD features -> endpoint rule -> device-side layout -> trim + unit variance -> ragged
+    #     MFCC+delta+delta2, queued as ONE asynchronous sequence (features/pipeline.py); the time is the
+    #     end-to-end HIP-event time per call, launches back to back, not a sum of stage timings ---
+    from features.pipeline import VadMfccPipeline
     rng = np.random.default_rng(7)
     sigs = []
     for _ in range(B):
@@ -156,36 +159,17 @@ def other_paths(dev):
         sigs.append(np.clip(np.round(x), -32768, 32767).astype(np.int16))
     so = np.concatenate([[0], np.cumsum([len(s_) for s_ in sigs])]).astype(np.int64)
     d_wave = torch.from_numpy(np.concatenate(sigs)).to(dev)
-    ep = EndpointPlan(16000, 0.03, 0.01)
-    lay = _BatchLayout(ep.L, ep.S, B, sample_offsets=so)
-    nf = lay.total_frames
-    d_amp = torch.empty(nf, dtype=torch.float64, device=dev)
-    d_zcr = torch.empty(nf, dtype=torch.int32, device=dev)
-    d_ep = torch.empty((B, 2), dtype=torch.int32, device=dev)
-    t_vad = timed(lambda: nat.check(lib.dsp_vad_features_batch(
-        d_wave.data_ptr(), nat.WAVE_I16, lay.p_sample, lay.p_frame, B, nf, 0, ep.L, ep.S, 0, d_amp.data_ptr(),
-        d_zcr.data_ptr(), st)))
-    t_rule = timed(lambda: nat.check(lib.dsp_endpoint_rule_batch(
-        d_amp.data_ptr(), d_zcr.data_ptr(), lay.p_frame, B, ep.L, float(ep.frame), float(ep.step), d_ep.data_ptr(), st)))
-    fr = d_ep.cpu().numpy().astype(np.int64)
-    lens = np.diff(so)
-    ends = np.stack([np.minimum((fr[:, 0] * ep.step * ep.rate).astype(np.int64), lens),
-                     np.minimum((fr[:, 1] * ep.step * ep.rate).astype(np.int64), lens)], axis=1)
-    dst = np.concatenate([[0], np.cumsum(ends[:, 1] - ends[:, 0])]).astype(np.int64)
-    d_so, d_dst = torch.from_numpy(so).to(dev), torch.from_numpy(dst).to(dev)
-    d_seg = torch.from_numpy(np.ascontiguousarray(ends.reshape(-1))).to(dev)
-    d_trim = torch.empty(int(dst[-1]), dtype=torch.float32, device=dev)
-    t_trim = timed(lambda: nat.check(lib.dsp_trim_scale_batch(
-        d_wave.data_ptr(), nat.WAVE_I16, d_so.data_ptr(), d_seg.data_ptr(), d_dst.data_ptr(), B, 1, d_trim.data_ptr(), st)))
-    fp = FeaturePlan(winfunc=np.hamming, **CFG)
-    flay = _BatchLayout(fp.L, fp.S, B, sample_offsets=dst)
-    o3 = torch.empty((flay.total_frames, 39), device=dev)
-    t_mfcc = timed(lambda: fp.run_raw(d_trim.data_ptr(), nat.WAVE_F32, flay, o3.data_ptr(), DELTA_N, st))
+    pipe = VadMfccPipeline(rate=16000, frame=0.03, step=0.01, unit_variance=True, winfunc=np.hamming,
+                           **{k: v for k, v in CFG.items() if k != 'samplerate'})
+    lay = pipe.prepare(so, DELTA_N)
+    d_feat = torch.empty((lay.frames_bound, lay.D), device=dev)
+    us = timed(lambda: pipe.launch(d_wave.data_ptr(), nat.WAVE_I16, lay, d_feat.data_ptr(), st))
+    frames = int(lay.d_frame_off.download((B + 1,), np.int64)[-1])
     out['configs3_vad_pipeline'] = {
-        'workload': f'{B} int16 utterances of 1-2 s at 16 kHz ({int(so[-1])} samples), burst in noise',
-        'vad_features_us': t_vad, 'endpoint_rule_us': t_rule, 'trim_scale_us': t_trim,
-        'ragged_mfcc_delta_us': t_mfcc, 'mfcc_frames': flay.total_frames,
-        'utterances_per_s': B / ((t_vad + t_rule + t_trim + t_mfcc) * 1e-6)}
+        'workload': f'{B} int16 utterances of 1-2 s at 16 kHz ({int(so[-1])} samples), burst in noise: VAD -> rule '
+                    f'-> trim + unit variance -> ragged MFCC+delta+delta2, no host round trip',
+        'end_to_end_us': us, 'mfcc_frames': frames, 'utterances_per_s': B / (us * 1e-6),
+        'input_GBps': 2.0 * int(so[-1]) / us / 1e3}
     return out
 
 
@@ -343,9 +327,11 @@ def main():
     # --- dominant kernel (fused MFCC) timed alone with events on the launch stream, same rotation ---
     lib = nat.load()
 
-    def mfcc_only(i):
+    cep = [torch.empty((B * T, plan.C), dtype=torch.float32, device=dev) for _ in range(2)]
+
+    def mfcc_only(i):   # dense [B*T, 13] cepstra: exactly the launch dsp_mfcc_delta_batch makes for a step
         nat.check(lib.dsp_features_batch(plan.plan.handle, waves[i % len(waves)].data_ptr(), nat.WAVE_F32, None,
-                                         None, B, B * T, N, nat.OUT_MFCC, outs[0][i & 1].data_ptr(), D,
+                                         None, B, B * T, N, nat.OUT_MFCC, cep[i & 1].data_ptr(), plan.C,
                                          None, sp))
 
     ksteps = 200

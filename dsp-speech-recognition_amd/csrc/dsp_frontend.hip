@@ -464,12 +464,60 @@ int dsp_mfcc_delta_batch(const dsp_plan* plan, const void* d_wave, int wave_dtyp
                          int64_t n_frames_total, int64_t uniform_samples, int32_t delta_n, float* d_out,
                          void* stream) {
     if (!plan) return fail(DSP_EINVAL, "plan is NULL");
+    if (delta_n < 1) return fail(DSP_EINVAL, "N must be an integer >= 1");  // base.py:71-72
     const int C = plan->C;
+    if (C <= 0) return fail(DSP_EINVAL, "plan has no mel/DCT tables");
+    int64_t uniform_frames = 0;
+    if (uniform_samples > 0) dsp_frame_count(uniform_samples, plan->L, plan->S, &uniform_frames);
+    hipStream_t st = (hipStream_t)stream;
+    // Two passes, every byte written once as part of a full line: the MFCC kernel writes DENSE cepstra
+    // [sum T, C] into a pooled scratch buffer, delta_rows_kernel turns them into whole 3C-float rows.
+    // (Writing the 52-byte cepstra straight into the 156-byte rows cost 1.5x write amplification and a
+    // strided re-read.)  Scratch above 256 MiB falls back to the in-place form.
+    const size_t lds = ((size_t)(DT_TILE + 4 * delta_n) + (size_t)(DT_TILE + 2 * delta_n)) * C * sizeof(float);
+    const size_t scratch_bytes = (size_t)n_frames_total * C * sizeof(float);
+    if (n_frames_total > 0 && n_utt > 0 && lds <= 64 * 1024 && scratch_bytes <= ((size_t)256 << 20)) {
+        const bool ragged = uniform_frames <= 0;
+        int64_t tiles = 0, blocks = 0;
+        if (!ragged) {
+            tiles = (uniform_frames + DT_TILE - 1) / DT_TILE;
+            blocks = tiles * n_utt;
+        } else {
+            if (!d_frame_offsets) return fail(DSP_EINVAL, "ragged batch needs d_frame_offsets");
+            blocks = n_frames_total / DT_TILE + n_utt;
+        }
+        if (blocks <= 0x7fffffff) {
+            const size_t tile_bytes = ragged ? (((size_t)n_utt + 1) * sizeof(int64_t) + 255) / 256 * 256 : 0;
+            DspWorkspace* w = dsp_workspace_pool().acquire(tile_bytes + scratch_bytes);
+            if (!w) return fail(DSP_EHIP, "workspace allocation failed");
+            int64_t* tile_off = ragged ? static_cast<int64_t*>(w->ptr) : nullptr;
+            float* cep = reinterpret_cast<float*>(static_cast<char*>(w->ptr) + tile_bytes);
+            int rc = dsp_features_batch(plan, d_wave, wave_dtype, d_sample_offsets, d_frame_offsets, n_utt,
+                                        n_frames_total, uniform_samples, DSP_OUT_MFCC, cep, (int64_t)C, nullptr, stream);
+            if (rc == DSP_OK) {
+                BatchGeom bg;
+                memset(&bg, 0, sizeof(bg));
+                bg.frame_off = d_frame_offsets;
+                bg.uniform_frames = uniform_frames > 0 ? uniform_frames : 0;
+                bg.total_frames = n_frames_total;
+                bg.n_utt = n_utt;
+                int den = 0;
+                for (int i = 1; i <= delta_n; ++i) den += i * i;
+                const float inv_den = (float)(1.0 / (2.0 * den));
+                if (ragged) prefix_ceil_kernel<<<1, 1024, 0, st>>>(d_frame_offsets, n_utt, 7, tile_off);
+                if (C == 13)
+                    delta_rows_kernel<13><<<(int)blocks, 256, lds, st>>>(cep, bg, C, delta_n, inv_den, d_out, (int32_t)tiles, tile_off);
+                else
+                    delta_rows_kernel<0><<<(int)blocks, 256, lds, st>>>(cep, bg, C, delta_n, inv_den, d_out, (int32_t)tiles, tile_off);
+                if (hipGetLastError() != hipSuccess) rc = fail(DSP_EHIP, "delta_rows_kernel launch failed");
+            }
+            if (dsp_workspace_pool().release(w, st) != 0 && rc == DSP_OK) rc = fail(DSP_EHIP, "workspace release failed");
+            return rc;
+        }
+    }
     int rc = dsp_features_batch(plan, d_wave, wave_dtype, d_sample_offsets, d_frame_offsets, n_utt,
                                 n_frames_total, uniform_samples, DSP_OUT_MFCC, d_out, 3 * (int64_t)C, nullptr, stream);
     if (rc != DSP_OK) return rc;
-    int64_t uniform_frames = 0;
-    if (uniform_samples > 0) dsp_frame_count(uniform_samples, plan->L, plan->S, &uniform_frames);
     return dsp_delta_batch(d_out, 3 * (int64_t)C, d_frame_offsets, n_utt, n_frames_total, uniform_frames, C,
                            delta_n, d_out + C, 3 * (int64_t)C, d_out + 2 * C, 3 * (int64_t)C, stream);
 }
@@ -525,6 +573,21 @@ int dsp_trim_scale_batch(const void* d_wave, int wave_dtype, const int64_t* d_sa
         trim_scale_kernel<DSP_WAVE_F32><<<n_utt, 256, 0, st>>>(d_wave, d_sample_offsets, d_segments, d_dst_offsets, unit_variance, d_out);
     else
         return fail(DSP_EINVAL, "unsupported wave_dtype %d", wave_dtype);
+    HIP_TRY(hipGetLastError());
+    return DSP_OK;
+}
+
+int dsp_endpoint_layout_batch(const int32_t* d_endpoints, const int64_t* d_sample_offsets, int32_t n_utt,
+                              double cfg_step, double rate, int32_t frame_len, int32_t frame_step,
+                              const int64_t* d_jitter, int64_t* d_segments, int64_t* d_dst_offsets,
+                              int64_t* d_frame_offsets, void* stream) {
+    if (!d_endpoints || !d_sample_offsets || !d_segments || !d_dst_offsets || !d_frame_offsets || n_utt <= 0)
+        return fail(DSP_EINVAL, "dsp_endpoint_layout_batch: bad arguments");
+    if (!(cfg_step > 0.0) || !(rate > 0.0) || frame_len <= 0 || frame_step <= 0)
+        return fail(DSP_EINVAL, "dsp_endpoint_layout_batch: step, rate, frame_len, frame_step must be > 0");
+    endpoint_layout_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(d_endpoints, d_sample_offsets, n_utt, cfg_step, rate,
+                                                               frame_len, frame_step, d_jitter, d_segments,
+                                                               d_dst_offsets, d_frame_offsets);
     HIP_TRY(hipGetLastError());
     return DSP_OK;
 }

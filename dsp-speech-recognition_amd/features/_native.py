@@ -62,6 +62,7 @@ SIGNATURES = {
                                          c_i32, c_vp, c_vp, c_vp]),
     'dsp_trim_scale_batch': (C.c_int, [c_vp, C.c_int, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     'dsp_endpoint_rule_batch': (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_f64, c_f64, c_vp, c_vp]),
+    'dsp_endpoint_layout_batch': (C.c_int, [c_vp, c_vp, c_i32, c_f64, c_f64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'dsp_pitch_scores_batch': (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_vp, c_i32,
                                          c_i32, c_i32, c_vp, c_vp]),
     'dsp_model_finalize_batch': (C.c_int, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
@@ -207,31 +208,44 @@ class DeviceBuffer:
 
 
 class Scratch:
-    """Grow-only named device buffers so single-utterance calls do not hipMalloc every time."""
+    """Grow-only named device buffers so single-utterance calls do not hipMalloc every time.
 
-    def __init__(self):
-        self._bufs = {}
-        self._lock = threading.Lock()
+    Slots are PER THREAD (and per device): every drop-in call uploads, launches and downloads on its
+    own thread's buffers, so concurrent callers never share a slot (ctypes releases the GIL during
+    the C calls).  A slot is only ever replaced by the thread that owns it, between its own calls;
+    the old buffer's hipFree waits for work still queued on it.  Results that outlive the call
+    (``download=False`` paths) are never scratch slots: they are owned DeviceBuffers.
+    """
 
-    def get(self, name, nbytes):
-        name = (current_device(), name)          # hipMalloc'ed memory belongs to one device
-        with self._lock:
-            b = self._bufs.get(name)
-            if b is None or b.nbytes < nbytes:
-                if b is not None:
-                    b.free()
-                b = DeviceBuffer(max(int(nbytes * 1.5), 4096))
-                self._bufs[name] = b
-            return b
+    def __init__(self, alloc=None):
+        self._tls = threading.local()
+        self._alloc = alloc or DeviceBuffer
+
+    def _bufs(self):
+        d = getattr(self._tls, 'bufs', None)
+        if d is None:
+            d = self._tls.bufs = {}
+        return d
+
+    def get(self, name, nbytes, device=None):
+        key = (current_device() if device is None else device, name)   # hipMalloc'ed memory belongs to one device
+        bufs = self._bufs()
+        b = bufs.get(key)
+        if b is None or b.nbytes < nbytes:
+            if b is not None:
+                b.free()
+            b = self._alloc(max(int(nbytes * 1.5), 4096))
+            bufs[key] = b
+        return b
 
 
 SCRATCH = Scratch()
 
 
-def device_array(name, arr):
-    """Upload a host array into the named scratch slot; returns the DeviceBuffer."""
+def device_array(name, arr, stream=None):
+    """Upload a host array into this thread's named scratch slot; returns the DeviceBuffer."""
     arr = np.ascontiguousarray(arr)
-    return SCRATCH.get(name, arr.nbytes).upload(arr)
+    return SCRATCH.get(name, arr.nbytes).upload(arr, stream)
 
 
 def as_wave(sig):

@@ -114,32 +114,50 @@ def model_finalize(mfcc0, frame_offsets, delta_n=3, max_len=200):
 
 
 class ModelFeatureBatch:
-    """Batched, device-resident form of RNNModel.get_batch_full (model.py:113-135, augment=False):
-    endpointing -> trim -> unit variance -> MFCC on the (1, N) view (no pre-emphasis, sigproc.py:185)
-    -> minus the utterance's scalar mean -> delta(3), delta(delta, 3) -> z-score of the static
-    coefficients -> [200, B, 39] zero padded.  Kernels come from the C ABI; the per-utterance
-    reductions (one mean, 13 means / variances) are torch segment sums on the same device."""
+    """Batched, device-resident form of RNNModel.get_batch_full (model.py:113-135): endpointing ->
+    (optional endpoint jitter, model.py:54-60) -> trim -> unit variance -> MFCC on the (1, N) view (no
+    pre-emphasis, sigproc.py:185) -> minus the utterance's scalar mean -> delta(3), delta(delta, 3) ->
+    z-score of the static coefficients -> [200, B, 39] zero padded.  Every step is a kernel behind the C
+    ABI, queued on one stream with no host round trip in between (features/pipeline.py)."""
 
     def __init__(self, rate, frame=0.03, step=0.01, nfft=1536, delta_n=3, max_len=200):
         from .pipeline import VadMfccPipeline
+        self.rate = rate
         self.pipe = VadMfccPipeline(rate=rate, frame=frame, step=step, unit_variance=True, winlen=frame,
                                     winstep=step, nfft=nfft, preemph=0.0, winfunc=np.hamming)
         self.delta_n, self.max_len = delta_n, max_len
 
-    def run(self, waves, sample_offsets):
-        """-> (inp [max_len, B, 39] torch tensor on cuda:0, len0 [B], endpoints [B, 2]).
-        Everything between the raw waveforms and ``inp`` runs in the library's kernels
-        (dsp_vad_features / endpoint_rule / trim_scale / features / model_finalize); torch only
-        owns the result tensor, so it can go straight into the classifier."""
+    def draw_jitter(self, n_utt, rng):
+        """The augmentation of model.py:54-60 for a whole batch: (-randint(0, 0.1 rate), +randint(0, 0.1
+        rate)) per utterance from ``rng`` (a random.Random, consumed in the reference's order: s_l then
+        s_r, utterance by utterance)."""
+        hi = int(0.1 * self.rate)
+        j = np.empty((n_utt, 2), dtype=np.int64)
+        for b in range(n_utt):
+            j[b, 0] = -rng.randint(0, hi)
+            j[b, 1] = rng.randint(0, hi)
+        return j
+
+    def run(self, waves, sample_offsets=None, jitter=None, layout=None):
+        """-> (inp [max_len, B, 39] torch tensor on the library's device, len0 [B], endpoints [B, 2]).
+        ``jitter``: int [B, 2] endpoint offsets (see draw_jitter) for the training path (augment=True);
+        None = test path.  torch only owns the result tensors, which go straight into the classifier."""
         import torch
         from . import _native as nat
+        from .batch import _is_device_tensor, _stream_ptr
         lib = nat.load()
-        (d_m0, flay), fo, ends = self.pipe.run(waves, sample_offsets, delta_n=0, download=False)
-        B, C = flay.n_utt, self.pipe.features.C
-        dev = torch.device('cuda', 0)
+        dev = waves.device if _is_device_tensor(waves) else torch.device('cuda', nat.current_device())
+        stream = torch.cuda.current_stream(dev)
+        with torch.cuda.stream(stream):
+            (d_m0, lay), _, _ = self.pipe.run(waves, sample_offsets, delta_n=0, download=False, layout=layout,
+                                              jitter=jitter)
+        B, C = lay.n_utt, self.pipe.features.C
         inp = torch.empty((self.max_len, B, 3 * C), dtype=torch.float32, device=dev)
         len0 = torch.empty(B, dtype=torch.int32, device=dev)
-        nat.check(lib.dsp_model_finalize_batch(d_m0.ptr, C, flay.p_frame, B, C, self.delta_n, self.max_len,
-                                               inp.data_ptr(), len0.data_ptr(), None))
-        nat.check(lib.dsp_stream_synchronize(None))     # d_m0 is library scratch: done before it is reused
-        return inp, len0.cpu().numpy(), ends
+        # host input: the pipeline ran on the legacy default stream, which orders against `stream`
+        st = _stream_ptr(stream) if _is_device_tensor(waves) else None
+        nat.check(lib.dsp_model_finalize_batch(d_m0.ptr, C, lay.d_frame_off.ptr, B, C, self.delta_n, self.max_len,
+                                               inp.data_ptr(), len0.data_ptr(), st))
+        seg = lay.d_seg.download((B, 2), np.int64, st)       # first host synchronisation of the call
+        nat.check(lib.dsp_stream_synchronize(st))            # d_m0 is freed on return: its consumer has finished
+        return inp, len0.cpu().numpy(), seg

@@ -1,23 +1,30 @@
 """BASELINE.json configs[3]: energy / ZCR endpointing feeding the feature extractor, batched, with
 variable-length outputs -- the device-side form of model.py:113-121 (endpoint_detect -> scale ->
-feature_extract_mfcc, augment=False).
+feature_extract_mfcc).
 
     waveforms (ragged, int16 or fp32)
       -> per-frame amplitude + ZCR, two-threshold rule        (dsp_vad_features_batch, dsp_endpoint_rule_batch)
-      -> [left, right) per utterance                           (8 bytes per utterance come to the host)
+      -> [left, right) in samples, trimmed-batch offsets       (dsp_endpoint_layout_batch, on the device)
       -> trimmed (optionally unit-variance) copy               (dsp_trim_scale_batch)
       -> MFCC (+ delta, delta-delta) of the trimmed clips      (dsp_mfcc_delta_batch, ragged fast path)
 
+Nothing comes back to the host in the middle: the frame-index -> sample-index conversion
+(endpoint.py:64), the clipping and both prefix sums run in one small kernel, and the feature kernels
+are sized by an upper bound (the frame count of the untrimmed clips) while the true offsets stay in
+device tables.  With a device tensor as input and ``download=False`` the whole call is a sequence of
+asynchronous launches on the caller's stream -- no allocation, copy or synchronisation once the layout
+of the batch (its sample offsets) has been prepared.
+
 The endpoint rule must have seen a whole utterance before its first trimmed frame can be cut, so
 the two framings (cfg.frame for VAD, winlen for MFCC) cannot share one pass; what is shared is the
-device-resident waveform -- nothing but the endpoints and the final features crosses PCIe.
+device-resident waveform.
 """
 from __future__ import annotations
 
 import numpy as np
 
 from . import _native as nat
-from .batch import EndpointPlan, FeaturePlan, _BatchLayout, _is_device_tensor, _wave_dtype_of
+from .batch import EndpointPlan, FeaturePlan, _BatchLayout, _is_device_tensor, _stream_ptr, _wave_dtype_of
 
 
 class _Borrowed:
@@ -27,8 +34,49 @@ class _Borrowed:
         self.ptr = int(ptr)
 
 
-def _ones(x):
-    return np.ones((x,))
+class _DeviceLayout:
+    """What FeaturePlan.run_raw needs, with the offsets living only on the device."""
+
+    def __init__(self, n_utt, d_sample, d_frame, frames_bound):
+        self.n_utt, self.d_sample, self.d_frame = n_utt, d_sample, d_frame
+        self.total_frames = int(frames_bound)        # upper bound; kernels read the truth from d_frame
+        self.uniform_samples = 0
+
+    @property
+    def p_sample(self):
+        return self.d_sample.ptr
+
+    @property
+    def p_frame(self):
+        return self.d_frame.ptr
+
+
+class PipelineLayout:
+    """Everything about a batch that depends only on its sample offsets: device copies of the offset
+    tables for the VAD framing, the frame-count bound of the feature stage, and the device buffers the
+    stages hand to each other.  Build once per batch shape with ``VadMfccPipeline.prepare`` and reuse:
+    ``run`` then allocates nothing."""
+
+    def __init__(self, pipe, sample_offsets, delta_n):
+        so = np.ascontiguousarray(sample_offsets, dtype=np.int64)
+        self.sample_offsets = so
+        self.n_utt = B = len(so) - 1
+        ep, fp = pipe.endpoint, pipe.features
+        self.vad = _BatchLayout(ep.L, ep.S, B, sample_offsets=so)
+        # trimming never lengthens a clip, and the frame count is monotone in the length
+        self.frames_bound = int(nat.frame_offsets(so, fp.L, fp.S)[-1])
+        self.total_samples = int(so[-1])
+        self.delta_n = int(delta_n)
+        self.D = fp.width(delta_n)
+        nf = self.vad.total_frames
+        self.d_amp = nat.DeviceBuffer(nf * 8)
+        self.d_zcr = nat.DeviceBuffer(nf * 4)
+        self.d_ep = nat.DeviceBuffer(B * 8)
+        self.d_seg = nat.DeviceBuffer(B * 16)
+        self.d_dst_off = nat.DeviceBuffer((B + 1) * 8)
+        self.d_frame_off = nat.DeviceBuffer((B + 1) * 8)
+        self.d_trim = nat.DeviceBuffer(max(self.total_samples, 1) * 4)
+        self.features = _DeviceLayout(B, self.d_dst_off, self.d_frame_off, self.frames_bound)
 
 
 class VadMfccPipeline:
@@ -41,57 +89,59 @@ class VadMfccPipeline:
         self.endpoint = EndpointPlan(rate, frame, step)
         self.features = FeaturePlan(**mfcc_kwargs)
 
-    def run(self, waves, sample_offsets, delta_n=2, download=True):
-        """waves: 1-D host array (int16 or float) or torch-ROCm tensor (int16 / float32) of concatenated
-        utterances.
-        Returns (features [sum T_b, D] fp32, frame_offsets [B+1], endpoints [B, 2] in samples);
-        with ``download=False`` the features stay on the device and the first element is the
-        (DeviceBuffer, _BatchLayout) pair of the result instead."""
+    def prepare(self, sample_offsets, delta_n=2):
         nat.require_device()
+        return PipelineLayout(self, sample_offsets, delta_n)
+
+    def launch(self, d_wave, wave_dtype, lay, d_out, stream=None, d_jitter=None):
+        """Queue the whole pipeline on `stream` (raw pointers, no host synchronisation, no allocation):
+        features land in `d_out` ([lay.frames_bound, D] fp32, rows packed by lay.d_frame_off)."""
         lib = nat.load()
-        so = np.ascontiguousarray(sample_offsets, dtype=np.int64)
-        B = len(so) - 1
+        st = _stream_ptr(stream)
+        ep, fp = self.endpoint, self.features
+        ep.run_raw(d_wave, wave_dtype, lay.vad, lay.d_amp.ptr, lay.d_zcr.ptr, lay.d_ep.ptr, st)
+        nat.check(lib.dsp_endpoint_layout_batch(lay.d_ep.ptr, lay.vad.p_sample, lay.n_utt, float(ep.step),
+                                                float(ep.rate), fp.L, fp.S, d_jitter, lay.d_seg.ptr,
+                                                lay.d_dst_off.ptr, lay.d_frame_off.ptr, st))
+        nat.check(lib.dsp_trim_scale_batch(d_wave, wave_dtype, lay.vad.p_sample, lay.d_seg.ptr, lay.d_dst_off.ptr,
+                                           lay.n_utt, 1 if self.unit_variance else 0, lay.d_trim.ptr, st))
+        fp.run_raw(lay.d_trim.ptr, nat.WAVE_F32, lay.features, d_out, lay.delta_n, st)
+
+    def run(self, waves, sample_offsets=None, delta_n=2, download=True, layout=None, jitter=None):
+        """waves: 1-D host array (int16 or float) or torch-ROCm tensor (int16 / float32) of concatenated
+        utterances; ``layout`` = a PipelineLayout from ``prepare`` (then sample_offsets is not needed).
+        ``jitter``: optional int [B, 2] sample offsets added to (left, right) before trimming
+        (model.py:54-60 draws them as -randint(0, 0.1 rate), +randint(0, 0.1 rate)).
+        Returns (features [sum T_b, D] fp32, frame_offsets [B+1], endpoints [B, 2] in samples);
+        with ``download=False`` nothing is copied or synchronised and the result is
+        ((DeviceBuffer of [frames_bound, D] rows, PipelineLayout), None, None): the true frame offsets
+        and endpoints are in layout.d_frame_off / layout.d_seg on the device."""
+        nat.require_device()
+        lay = layout if layout is not None else self.prepare(sample_offsets, delta_n)
+        stream = None
         if _is_device_tensor(waves):                # torch-ROCm tensor: nothing crosses PCIe
+            import torch
             if not waves.is_contiguous():
                 waves = waves.contiguous()
+            if waves.device.index != nat.current_device():
+                raise nat.DspError(f'waveforms live on cuda:{waves.device.index}, the library is on device '
+                                   f'{nat.current_device()} (dsp_set_device)')
             dtype = _wave_dtype_of(waves)
             d_wave = _Borrowed(waves.data_ptr())
+            stream = torch.cuda.current_stream(waves.device)
         else:
             wave, dtype = nat.as_wave(np.asarray(waves).reshape(-1))
             d_wave = nat.device_array('batch_wave', wave)
-
-        # 1. endpoints (frame indices -> sample indices exactly as endpoint.py:64)
-        ep = self.endpoint
-        lay = _BatchLayout(ep.L, ep.S, B, sample_offsets=so, scratch='pipe_vad')
-        nf = lay.total_frames
-        d_amp = nat.SCRATCH.get('ep_amp', nf * 8)
-        d_zcr = nat.SCRATCH.get('ep_zcr', nf * 4)
-        d_ep = nat.SCRATCH.get('ep_batch', B * 8)
-        ep.run_raw(d_wave.ptr, dtype, lay, d_amp.ptr, d_zcr.ptr, d_ep.ptr, None)
-        frames = d_ep.download((B, 2), np.int32)
-        # int((idx * step) * rate), the fp64 product order of endpoint.py:64, vectorised; numpy
-        # slicing sig[left:right] clips at the end of the clip
-        ends = ((frames.astype(np.float64) * ep.step) * ep.rate).astype(np.int64)
-        ends = np.minimum(ends, np.diff(so)[:, None])
-
-        # 2. trimmed copy on the device
-        lens = np.maximum(ends[:, 1] - ends[:, 0], 0)
-        dst_off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
-        total = int(dst_off[-1])
-        d_src_off = nat.device_array('trim_src_off', so)
-        d_seg = nat.device_array('trim_seg', np.ascontiguousarray(ends.reshape(-1)))
-        d_dst_off = nat.device_array('trim_dst_off', dst_off)
-        d_trim = nat.SCRATCH.get('trim_wave', max(total, 1) * 4)
-        nat.check(lib.dsp_trim_scale_batch(d_wave.ptr, dtype, d_src_off.ptr, d_seg.ptr, d_dst_off.ptr, B,
-                                           1 if self.unit_variance else 0, d_trim.ptr, None))
-
-        # 3. features of the trimmed clips (ragged layout)
-        fp = self.features
-        flay = _BatchLayout(fp.L, fp.S, B, sample_offsets=dst_off, scratch='pipe_mfcc')
-        D = fp.width(delta_n)
-        d_out = nat.SCRATCH.get('batch_out', flay.total_frames * D * 4)
-        fp.run_raw(d_trim.ptr, nat.WAVE_F32, flay, d_out.ptr, delta_n, None)
+        d_jit = None
+        if jitter is not None:
+            j = np.ascontiguousarray(jitter, dtype=np.int64).reshape(lay.n_utt, 2)
+            d_jit = nat.device_array('pipe_jitter', j, _stream_ptr(stream)).ptr
+        d_out = nat.DeviceBuffer(max(lay.frames_bound, 1) * lay.D * 4)      # owned by the result
+        self.launch(d_wave.ptr, dtype, lay, d_out.ptr, stream, d_jit)
         if not download:
-            return (d_out, flay), flay.frame_offsets, ends
-        out = d_out.download((flay.total_frames, D), np.float32)
-        return out, flay.frame_offsets, ends
+            return (d_out, lay), None, None
+        st = _stream_ptr(stream)
+        fo = lay.d_frame_off.download((lay.n_utt + 1,), np.int64, st)
+        seg = lay.d_seg.download((lay.n_utt, 2), np.int64, st)
+        out = d_out.download((int(fo[-1]), lay.D), np.float32, st)
+        return out, fo, seg

@@ -184,6 +184,24 @@ int dsp_trim_scale_batch(const void* d_wave, int wave_dtype, const int64_t* d_sa
                          const int64_t* d_segments, const int64_t* d_dst_offsets, int32_t n_utt,
                          int32_t unit_variance, float* d_out, void* stream);
 
+/*
+ * Device-side glue between dsp_endpoint_rule_batch and dsp_trim_scale_batch / dsp_features_batch, so that
+ * the endpoint -> trim -> features pipeline of model.py:113-121 needs no host round trip:
+ *   d_segments[2b], [2b+1] = int((left * cfg.step) * rate), int((right * cfg.step) * rate) in fp64, that
+ *                            order, truncated (endpoint.py:64), clipped to the clip length as numpy slicing
+ *                            sig[left:right] does (model.py:62); with d_jitter != NULL the per-utterance
+ *                            offsets d_jitter[2b] (added to left, i.e. -s_l) and d_jitter[2b+1] (+s_r) of
+ *                            model.py:54-60 are applied first and negatives raised to 0;
+ *   d_dst_offsets[B+1]     = exclusive prefix of the trimmed lengths;
+ *   d_frame_offsets[B+1]   = exclusive prefix of their frame counts at (frame_len, frame_step).
+ * Ragged feature calls that follow may pass an upper bound as n_frames_total (e.g. the frame count of the
+ * untrimmed clips): kernels take the true totals from d_frame_offsets.
+ */
+int dsp_endpoint_layout_batch(const int32_t* d_endpoints, const int64_t* d_sample_offsets, int32_t n_utt,
+                              double cfg_step, double rate, int32_t frame_len, int32_t frame_step,
+                              const int64_t* d_jitter, int64_t* d_segments, int64_t* d_dst_offsets,
+                              int64_t* d_frame_offsets, void* stream);
+
 /* ---- model.py glue behind the feature call ----------------------------- */
 /*
  * What model.py:66-88 does to mfcc0 = mfcc(...) of every utterance, and the [200, B, 39] layout of

@@ -47,6 +47,9 @@ def api():
     return a
 
 
+# z-scored static coefficients of the model pipeline (model.py:78): measured worst case, see DESIGN.md section 8
+M0_TOL = 2e-3
+
 @pytest.mark.parametrize('case', CASES, ids=[c['name'] for c in CASES])
 def test_gpu_matches_reference(case, golden, api):
     if case['fn'] == 'pitch_detect_sr' and not hasattr(api, 'pitch_detect_sr'):
@@ -69,5 +72,8 @@ def test_gpu_matches_reference(case, golden, api):
             assert np.max(np.abs(val)) <= 1e-5, (case['name'], key, np.max(np.abs(val)))
             continue
         err = normwise(val, ref)
-        tol = 2e-3 if case['fn'] == 'model_feature_extract_mfcc' and key == 'm0' else TOL
+        is_m0 = case['fn'] == 'model_feature_extract_mfcc' and key == 'm0'
+        from conftest import record
+        record('golden_model_m0' if is_m0 else 'golden_float_outputs', err)
+        tol = M0_TOL if is_m0 else TOL
         assert err <= tol, (case['name'], key, err)

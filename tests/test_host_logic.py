@@ -161,3 +161,40 @@ def test_pitch_host_helpers_match_oracle():
     assert np.array_equal(np.asarray(gp.smooth(g, 2)), dsp_oracle.smooth(g, 2))
     assert gp.robust_max_pitch(g) == dsp_oracle.robust_max_pitch(g)
     assert gp.max_pitch(g[:3]) == dsp_oracle.max_pitch(g[:3])
+
+
+def test_scratch_slots_are_per_thread_and_never_shared():
+    """The slot-leasing logic behind the drop-in calls (features/_native.py), without a GPU: slots are
+    keyed by (thread, device, name), grow by replacement inside their own thread only, and two threads
+    asking for the same name never see the same buffer."""
+    import threading
+    from features import _native as nat
+
+    class Fake:
+        live = 0
+
+        def __init__(self, nbytes):
+            self.nbytes, self.freed = nbytes, False
+            Fake.live += 1
+
+        def free(self):
+            assert not self.freed
+            self.freed = True
+            Fake.live -= 1
+
+    sc = nat.Scratch(alloc=Fake)
+    a = sc.get('wave', 1000, device=0)
+    assert sc.get('wave', 500, device=0) is a and not a.freed           # reuse, no shrink
+    b = sc.get('wave', 100000, device=0)
+    assert b is not a and a.freed and b.nbytes >= 100000                  # growth replaces in the owner thread
+    assert sc.get('wave', 10, device=1) is not b                          # per device
+    seen = {}
+
+    def other():
+        seen['buf'] = sc.get('wave', 10, device=0)
+
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    assert seen['buf'] is not b and not b.freed                           # another thread: its own slot
+    assert Fake.live == 3

@@ -44,7 +44,7 @@ def main():
     def mfcc_only(i):
         k = i % len(streams)
         nat.check(lib.dsp_features_batch(plan.plan.handle, waves[i % 8].data_ptr(), nat.WAVE_F32, None, None, B,
-                                         B * T, N, nat.OUT_MFCC, outs[k].data_ptr(), 39, None,
+                                         B * T, N, nat.OUT_MFCC, outs[k].data_ptr(), 13, None,
                                          streams[k].cuda_stream))
 
     def full(i):
