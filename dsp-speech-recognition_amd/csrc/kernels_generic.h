@@ -383,6 +383,267 @@ __global__ __launch_bounds__(256) void delta_rows_kernel(const float* __restrict
     }
 }
 
+template <int DTYPE>
+__global__ __launch_bounds__(256) void preemphasis_kernel(const void* __restrict__ wave, const int64_t* __restrict__ off,
+                                                          int32_t n_utt, int64_t total, float coeff,
+                                                          float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t u = dsp_find_utt(off, n_utt, i);
+        float v = dsp_load_sample<DTYPE>(wave, i);
+        if (i > off[u]) v = fmaf(-coeff, dsp_load_sample<DTYPE>(wave, i - 1), v);
+        out[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_columns_kernel(float* __restrict__ x, int64_t rows, int32_t cols,
+                                                            const float* __restrict__ scale) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x)
+        x[i] *= scale[i % cols];
+}
+
+// endpoint.get_amplitude / get_zcr (endpoint.py:109-126,182-198) on rectangular frames
+// (sigproc.to_frames, sigproc.py:11-19).  One wavefront per frame, fp64 accumulation.
+template <int DTYPE>
+__global__ __launch_bounds__(256) void vad_features_kernel(const void* __restrict__ wave, BatchGeom bg, int32_t L,
+                                                           int32_t S, int32_t use_sq, double* __restrict__ amp_sum,
+                                                           int32_t* __restrict__ zcr) {
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t n_tiles = (bg.total_frames + 3) / 4;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t g = tile * 4 + wid;
+        if (g >= bg.total_frames) continue;
+        int32_t utt;
+        int64_t t, s0, nsamp;
+        dsp_locate(bg, g, utt, t, s0, nsamp);
+        const int64_t first = t * (int64_t)S;
+        double acc = 0.0;
+        int32_t cnt = 0;
+        for (int n = lane; n < L; n += 64) {
+            const int64_t pos = first + n;
+            const float a = pos < nsamp ? dsp_load_sample<DTYPE>(wave, s0 + pos) : 0.f;
+            acc += use_sq ? (double)a * (double)a : (double)fabsf(a);
+            if (n + 1 < L) {
+                const float b = pos + 1 < nsamp ? dsp_load_sample<DTYPE>(wave, s0 + pos + 1) : 0.f;
+                cnt += ((a > 0.f && b < 0.f) || (a < 0.f && b > 0.f)) ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            acc += __shfl_xor(acc, o, 64);
+            cnt += __shfl_xor(cnt, o, 64);
+        }
+        if (lane == 0) {
+            amp_sum[g] = acc;
+            zcr[g] = cnt;
+        }
+    }
+}
+
+#define DSP_MAX_SIL 128
+
+// endpoint.amplitude_rule (endpoint.py:133-179, use_acr=False): only the first segment's start and
+// the last segment's end are consumed by basic_endpoint_detection (endpoint.py:43,49).
+template <typename AmpT, typename SilT>
+__device__ __forceinline__ void amplitude_rule_dev(AmpT amp, int64_t T, double inv_L, double mh,
+                                                   double th, int n_l, int n_r, double sigma, double cfg_frame,
+                                                   SilT sil, int64_t& left, int64_t& right) {
+    int ns = 0;
+    const int64_t cl = n_l < T ? n_l : T;                   // amp[:n_l]
+    for (int64_t i = 0; i < cl; ++i) sil[ns++] = amp[i] * inv_L;
+    const int64_t cr = (n_r == 0 || n_r > T) ? T : n_r;     // amp[-n_r:]  (-0 slices the whole list)
+    for (int64_t i = T - cr; i < T; ++i) sil[ns++] = amp[i] * inv_L;
+    for (int i = 1; i < ns; ++i) {                          // insertion sort, ns <= 128
+        double v = sil[i];
+        int j = i - 1;
+        while (j >= 0 && sil[j] > v) { sil[j + 1] = sil[j]; --j; }
+        sil[j + 1] = v;
+    }
+    const int m = ns - 2 > 0 ? ns - 2 : 0;                  // sorted(sil)[:-2]
+    double mean = 0.0, var = 0.0;
+    for (int i = 0; i < m; ++i) mean += sil[i];
+    mean = m > 0 ? mean / m : __longlong_as_double(0x7ff8000000000000LL);
+    for (int i = 0; i < m; ++i) var += (sil[i] - mean) * (sil[i] - mean);
+    const double sd = m > 0 ? sqrt(var / m) : mean;
+    double amax = amp[0] * inv_L;
+    for (int64_t i = 1; i < T; ++i) { double v = amp[i] * inv_L; amax = v > amax ? v : amax; }
+    const double T_H = th / cfg_frame;
+    const double M_L = mean + sigma * sd;
+    const double a = amax * mh;
+    const double M_H = (M_L > a) ? M_L : a;                 // python max(a, M_L): NaN M_L loses
+    bool any = false;
+    int64_t i = 0;
+    while (i < T) {
+        if (amp[i] * inv_L >= M_H) {
+            int64_t j = i, k = i;
+            while (k < T && amp[k] * inv_L > M_H) ++k;
+            if ((double)(k - j) < T_H) {
+                i = k;
+            } else {
+                while (j > 0 && amp[j] * inv_L > M_L) --j;
+                while (k < T && amp[k] * inv_L > M_L) ++k;
+                if (!any) { left = j; any = true; }
+                right = k;
+                i = k;
+            }
+        }
+        ++i;
+    }
+    if (!any) { left = 0; right = T; }
+}
+
+// endpoint.zcr_rule (endpoint.py:201-220; l_sil = 0 -> front slice empty, r_sil = 0.1) and the
+// <50-frame fallback of endpoint.py:60-62.
+template <typename ZcrT>
+__device__ __forceinline__ void endpoint_zcr_rule(ZcrT z, int64_t T, int64_t left, int64_t right, int n_sil,
+                                                  double cfg_frame, int32_t* __restrict__ out2) {
+    const double max_shift = 0.400 / cfg_frame;
+    const int64_t cr = (n_sil == 0 || n_sil > T) ? T : n_sil;
+    double mu = 0.0, var = 0.0;
+    for (int64_t i = T - cr; i < T; ++i) mu += (double)z[i];
+    mu /= (double)cr;
+    for (int64_t i = T - cr; i < T; ++i) var += ((double)z[i] - mu) * ((double)z[i] - mu);
+    const double thres = mu + 3.0 * sqrt(var / (double)cr);
+    int64_t j = left;
+    while (j > 0 && (double)(left - j) <= max_shift && (double)z[j] > thres) --j;
+    int64_t k = right;
+    while (k < T && (double)(k - right) <= max_shift && (double)z[k] > thres) ++k;
+    if (k - j < 50) { j = 0; k = T; }                       // endpoint.py:60-62
+    out2[0] = (int32_t)j;
+    out2[1] = (int32_t)k;
+}
+
+template <typename AmpT, typename ZcrT, typename SilT>
+__device__ __forceinline__ void endpoint_rule_body(AmpT amp, ZcrT z, SilT sil, int64_t T, double inv_L,
+                                                   double cfg_frame, double cfg_step, int32_t* __restrict__ out2) {
+    const int n_sil = (int)(0.100 / cfg_step);              // int(l_sil / cfg.step), endpoint.py:151
+    int64_t left = 0, right = T;
+    amplitude_rule_dev(amp, T, inv_L, 0.25, 0.100, n_sil, n_sil, 3.0, cfg_frame, sil, left, right);
+    if (right - left < 50)                                  // endpoint.py:44-45
+        amplitude_rule_dev(amp, T, inv_L, 0.125, 0.100, n_sil, n_sil, 3.0, cfg_frame, sil, left, right);
+    endpoint_zcr_rule(z, T, left, right, n_sil, cfg_frame, out2);
+}
+
+#define DSP_RULE_LDS_FRAMES 2048   // utterances up to this many frames are scanned out of LDS
+
+// One wavefront per utterance: the wave copies the utterance's amp / zcr rows into LDS (coalesced),
+// then lane 0 runs the sequential state machines against LDS instead of HBM (the scan is a chain of
+// dependent loads: ~1 us each from HBM, ~0.05 us from LDS).
+__global__ __launch_bounds__(64) void endpoint_rule_kernel(const double* __restrict__ amp_sum,
+                                                           const int32_t* __restrict__ zcr,
+                                                           const int64_t* __restrict__ frame_off, int32_t n_utt,
+                                                           int32_t L, double cfg_frame, double cfg_step,
+                                                           int32_t* __restrict__ endpoints) {
+    __shared__ double s_amp[DSP_RULE_LDS_FRAMES];
+    __shared__ int32_t s_zcr[DSP_RULE_LDS_FRAMES];
+    __shared__ double s_sil[DSP_MAX_SIL];
+    __shared__ double s_sorted[DSP_MAX_SIL];
+    __shared__ double s_thr[3];
+    __shared__ uint8_t s_cls[DSP_RULE_LDS_FRAMES];
+    const int32_t b = blockIdx.x;
+    if (b >= n_utt) return;
+    const int64_t base = frame_off[b];
+    const int64_t T = frame_off[b + 1] - base;
+    const double* amp = amp_sum + base;
+    const int32_t* z = zcr + base;
+    const double inv_L = 1.0 / (double)L;
+    if (T <= DSP_RULE_LDS_FRAMES) {
+        // (1) whole wave: copy the rows, running maximum
+        const int lane = threadIdx.x;
+        double mx = amp[0] * inv_L;
+        for (int i = lane; i < (int)T; i += 64) {
+            const double v = amp[i] * inv_L;   // the per-frame mean, scaled once instead of at every use
+            s_amp[i] = v;
+            s_zcr[i] = z[i];
+            mx = v > mx ? v : mx;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double other = __shfl_xor(mx, o, 64);
+            mx = other > mx ? other : mx;
+        }
+        __syncthreads();
+        // (2) silence window amp[:n] + amp[-n:] (endpoint.py:151-153), rank sort (stable: equal keys keep order)
+        const int n_sil = (int)(0.100 / cfg_step);
+        const int cl = n_sil < (int)T ? n_sil : (int)T;
+        const int cr = (n_sil == 0 || n_sil > (int)T) ? (int)T : n_sil;
+        const int ns = cl + cr;
+        for (int k = lane; k < ns; k += 64) s_sil[k] = k < cl ? s_amp[k] : s_amp[(int)T - cr + (k - cl)];
+        __syncthreads();
+        for (int k = lane; k < ns; k += 64) {
+            const double v = s_sil[k];
+            int rank = 0;
+            for (int j = 0; j < ns; ++j) {
+                const double w = s_sil[j];
+                rank += (w < v || (w == v && j < k)) ? 1 : 0;
+            }
+            s_sorted[rank] = v;
+        }
+        __syncthreads();
+        // (3) lane 0: statistics of sorted(sil)[:-2] in the reference's order, the two thresholds
+        if (lane == 0) {
+            const int m = ns - 2 > 0 ? ns - 2 : 0;
+            double mean = 0.0, var = 0.0;
+            for (int i = 0; i < m; ++i) mean += s_sorted[i];
+            mean = m > 0 ? mean / m : __longlong_as_double(0x7ff8000000000000LL);
+            for (int i = 0; i < m; ++i) var += (s_sorted[i] - mean) * (s_sorted[i] - mean);
+            const double sd = m > 0 ? sqrt(var / m) : mean;
+            const double M_L = mean + 3.0 * sd;
+            const double a1 = mx * 0.25, a2 = mx * 0.125;            // mh, and the retry of endpoint.py:44-45
+            s_thr[0] = M_L;
+            s_thr[1] = (M_L > a1) ? M_L : a1;                         // python max(a, M_L): NaN M_L loses
+            s_thr[2] = (M_L > a2) ? M_L : a2;
+        }
+        __syncthreads();
+        // (4) whole wave: every comparison the scans can ask for, one byte per frame
+        {
+            const double M_L = s_thr[0], M_H1 = s_thr[1], M_H2 = s_thr[2];
+            for (int i = lane; i < (int)T; i += 64) {
+                const double v = s_amp[i];
+                s_cls[i] = (uint8_t)((v > M_L ? 1 : 0) | (v > M_H1 ? 2 : 0) | (v >= M_H1 ? 4 : 0) |
+                                     (v > M_H2 ? 8 : 0) | (v >= M_H2 ? 16 : 0));
+            }
+        }
+        __syncthreads();
+        if (lane != 0) return;
+        // (5) lane 0: the two-threshold scan (endpoint.py:155-179) on the class bytes
+        const double T_H = 0.100 / cfg_frame;
+        int64_t left = 0, right = T;
+        for (int pass = 0; pass < 2; ++pass) {
+            const uint8_t hi = pass == 0 ? 2 : 8, ge = pass == 0 ? 4 : 16;
+            bool any = false;
+            int64_t i = 0;
+            while (i < T) {
+                if (s_cls[i] & ge) {
+                    int64_t j = i, k = i;
+                    while (k < T && (s_cls[k] & hi)) ++k;
+                    if ((double)(k - j) < T_H) {
+                        i = k;
+                    } else {
+                        while (j > 0 && (s_cls[j] & 1)) --j;
+                        while (k < T && (s_cls[k] & 1)) ++k;
+                        if (!any) { left = j; any = true; }
+                        right = k;
+                        i = k;
+                    }
+                }
+                ++i;
+            }
+            if (!any) { left = 0; right = T; }
+            if (right - left >= 50) break;                             // endpoint.py:44-45
+        }
+        endpoint_zcr_rule(s_zcr, T, left, right, n_sil, cfg_frame, endpoints + 2 * b);
+    } else {
+        if (threadIdx.x != 0) return;
+        endpoint_rule_body(amp, z, s_sil, T, inv_L, cfg_frame, cfg_step, endpoints + 2 * b);
+    }
+}
+
+// Endpoint-trimmed copy of a ragged batch (model.py:52-64 without augmentation): utterance b keeps
+// samples [lo_b, hi_b) and is divided by its population standard deviation when `unit_variance`
+// (sklearn scale(with_mean=False), zero std -> 1).  One workgroup per utterance; fp64 statistics.
 // configs[3] glue, all on the device: endpoint frame indices -> what the trim and feature kernels need.
 //   seg[b]      = (int((left  * step) * rate), int((right * step) * rate)) clipped to the clip length
 //                 (endpoint.py:64: fp64 products in that order, truncation; numpy slicing clips at the end;
