@@ -255,7 +255,7 @@ def test_fast_kernel_instantiations(cfg, dtype):
     assert nat.load().dsp_plan_has_fast_path(plan.plan.handle) == 1
     # 64 filters on a 257-bin spectrum: the lowest ones are 1-2 bins wide and their logs amplify the
     # fp32 FFT noise floor (the generic kernel shows 5.5e-5 on the same data)
-    tol = 3e-4 if full['nfilt'] >= 64 else TOL
+    tol = 3e-4 if full['nfilt'] >= 64 else TOL      # measured 1.51e-4 at 64 filters (parity_measured.json): 2x
     dense = _batch(51, 24, 8000, dtype=dtype)
     out, fo = plan.mfcc_batch(dense, delta_n=2)
     lens = [8000, 513, 4097, 1, 7999, 12001, 640]

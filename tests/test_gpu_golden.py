@@ -47,8 +47,9 @@ def api():
     return a
 
 
-# z-scored static coefficients of the model pipeline (model.py:78): measured worst case, see DESIGN.md section 8
-M0_TOL = 2e-3
+# z-scored static coefficients of the model pipeline (model.py:78): measured 7.1e-6 on the reference's own
+# golden (gpurun_out/parity_measured.json, round 2) -- no exception to the 1e-4 bar is needed
+M0_TOL = 1e-4
 
 @pytest.mark.parametrize('case', CASES, ids=[c['name'] for c in CASES])
 def test_gpu_matches_reference(case, golden, api):

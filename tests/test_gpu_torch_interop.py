@@ -67,7 +67,7 @@ def test_device_features_feed_torch_rnn():
     assert np.array_equal(logits_gpu.argmax(1), logits_ref.argmax(1))
 
 
-M0_TOL = 2e-3   # measured worst case x 2, see DESIGN.md section 8 (gpurun_out/parity_measured.json)
+M0_TOL = 1e-4   # measured 1.1e-5 (gpurun_out/parity_measured.json, round 2): the 1e-4 bar holds, no exception
 
 
 def test_model_feature_batch_matches_reference_pipeline(golden):
