@@ -351,10 +351,10 @@ static int launch_generic(const dsp_plan* plan, const void* d_wave, int wave_dty
     return DSP_OK;
 }
 
-int dsp_features_batch(const dsp_plan* plan, const void* d_wave, int wave_dtype,
-                       const int64_t* d_sample_offsets, const int64_t* d_frame_offsets, int32_t n_utt,
-                       int64_t n_frames_total, int64_t uniform_samples, int out_kind, float* d_out,
-                       int64_t ld_out, float* d_out2, void* stream) {
+static int features_batch_impl(const dsp_plan* plan, const void* d_wave, int wave_dtype,
+                               const int64_t* d_sample_offsets, const int64_t* d_frame_offsets, int32_t n_utt,
+                               int64_t n_frames_total, int64_t uniform_samples, int out_kind, float* d_out,
+                               int64_t ld_out, float* d_out2, void* stream, const DspRaggedTables* pre) {
     if (!plan || !d_out) return fail(DSP_EINVAL, "plan/d_out is NULL");
     {
         int dev = -1;
@@ -392,14 +392,22 @@ int dsp_features_batch(const dsp_plan* plan, const void* d_wave, int wave_dtype,
         DspWorkspace* view = fused_kernel_view(fg, fw, wave_dtype, st);
         int frc = 1;   // 1 = no fused kernel took it
         if (fast512_applicable(plan, fg, fw, wave_dtype))
-            frc = fast512_launch(plan, fw, wave_dtype, fg, d_out, ld_out, st);
+            frc = fast512_launch(plan, fw, wave_dtype, fg, d_out, ld_out, st, pre);
         else if (fast1536_applicable(plan, fg, fw, wave_dtype))
-            frc = fast1536_launch(plan, fw, wave_dtype, fg, d_out, ld_out, st);
+            frc = fast1536_launch(plan, fw, wave_dtype, fg, d_out, ld_out, st, pre);
         if (view && dsp_workspace_pool().release(view, st) != 0 && frc == DSP_OK) frc = DSP_EHIP;
         if (frc == DSP_OK) return DSP_OK;
         if (frc < 0) return fail(frc, "fused kernel launch failed");
     }
     return launch_generic(plan, d_wave, wave_dtype, bg, out_kind, d_out, ld_out, d_out2, st);
+}
+
+int dsp_features_batch(const dsp_plan* plan, const void* d_wave, int wave_dtype,
+                       const int64_t* d_sample_offsets, const int64_t* d_frame_offsets, int32_t n_utt,
+                       int64_t n_frames_total, int64_t uniform_samples, int out_kind, float* d_out,
+                       int64_t ld_out, float* d_out2, void* stream) {
+    return features_batch_impl(plan, d_wave, wave_dtype, d_sample_offsets, d_frame_offsets, n_utt, n_frames_total,
+                               uniform_samples, out_kind, d_out, ld_out, d_out2, stream, nullptr);
 }
 
 int dsp_delta_batch(const float* d_in, int64_t ld_in, const int64_t* d_frame_offsets, int32_t n_utt,
@@ -487,13 +495,27 @@ int dsp_mfcc_delta_batch(const dsp_plan* plan, const void* d_wave, int wave_dtyp
             blocks = n_frames_total / DT_TILE + n_utt;
         }
         if (blocks <= 0x7fffffff) {
-            const size_t tile_bytes = ragged ? (((size_t)n_utt + 1) * sizeof(int64_t) + 255) / 256 * 256 : 0;
-            DspWorkspace* w = dsp_workspace_pool().acquire(tile_bytes + scratch_bytes);
+            // ragged: the delta tile table and the fused MFCC kernel's group tables come from ONE small launch
+            const int gshift = plan->d_fast ? 3 : (plan->d_fast1536 ? 2 : 0);
+            const int64_t gbound = gshift ? (n_frames_total >> gshift) + n_utt : 0;
+            auto pad256 = [](size_t b) { return (b + 255) / 256 * 256; };
+            const size_t tile_bytes = ragged ? pad256(((size_t)n_utt + 1) * sizeof(int64_t)) : 0;
+            const size_t goff_bytes = ragged && gshift ? pad256(((size_t)n_utt + 1) * sizeof(int32_t)) : 0;
+            const size_t gutt_bytes = ragged && gshift ? pad256((size_t)gbound * sizeof(int32_t)) : 0;
+            DspWorkspace* w = dsp_workspace_pool().acquire(tile_bytes + goff_bytes + gutt_bytes + scratch_bytes);
             if (!w) return fail(DSP_EHIP, "workspace allocation failed");
-            int64_t* tile_off = ragged ? static_cast<int64_t*>(w->ptr) : nullptr;
-            float* cep = reinterpret_cast<float*>(static_cast<char*>(w->ptr) + tile_bytes);
-            int rc = dsp_features_batch(plan, d_wave, wave_dtype, d_sample_offsets, d_frame_offsets, n_utt,
-                                        n_frames_total, uniform_samples, DSP_OUT_MFCC, cep, (int64_t)C, nullptr, stream);
+            char* wp = static_cast<char*>(w->ptr);
+            int64_t* tile_off = ragged ? reinterpret_cast<int64_t*>(wp) : nullptr;
+            DspRaggedTables pre;
+            pre.shift = gshift;
+            pre.group_off = reinterpret_cast<int32_t*>(wp + tile_bytes);
+            pre.group_utt = reinterpret_cast<int32_t*>(wp + tile_bytes + goff_bytes);
+            float* cep = reinterpret_cast<float*>(wp + tile_bytes + goff_bytes + gutt_bytes);
+            const bool have_pre = ragged && gshift != 0 && gbound <= 0x3fffffff;
+            if (have_pre) f512_build_group_tables(d_frame_offsets, n_utt, gshift, pre.group_off, pre.group_utt, st, tile_off);
+            int rc = features_batch_impl(plan, d_wave, wave_dtype, d_sample_offsets, d_frame_offsets, n_utt,
+                                         n_frames_total, uniform_samples, DSP_OUT_MFCC, cep, (int64_t)C, nullptr, stream,
+                                         have_pre ? &pre : nullptr);
             if (rc == DSP_OK) {
                 BatchGeom bg;
                 memset(&bg, 0, sizeof(bg));
@@ -504,7 +526,7 @@ int dsp_mfcc_delta_batch(const dsp_plan* plan, const void* d_wave, int wave_dtyp
                 int den = 0;
                 for (int i = 1; i <= delta_n; ++i) den += i * i;
                 const float inv_den = (float)(1.0 / (2.0 * den));
-                if (ragged) prefix_ceil_kernel<<<1, 1024, 0, st>>>(d_frame_offsets, n_utt, 7, tile_off);
+                if (ragged && !have_pre) prefix_ceil_kernel<<<1, 1024, 0, st>>>(d_frame_offsets, n_utt, 7, tile_off);
                 if (C == 13)
                     delta_rows_kernel<13><<<(int)blocks, 256, lds, st>>>(cep, bg, C, delta_n, inv_den, d_out, (int32_t)tiles, tile_off);
                 else

@@ -606,7 +606,7 @@ static int fast1536_launch_k(const F1536Params& P, const void* d_wave, const Bat
 
 template <int NI, int NC, int NSTAGE>
 static int fast1536_launch_t(F1536Params P, const void* d_wave, int dtype, const BatchGeom& bg, float* d_out,
-                             int64_t ld_out, hipStream_t st) {
+                             int64_t ld_out, hipStream_t st, const DspRaggedTables* pre = nullptr) {
     if (bg.uniform_samples > 0) {
         P.groups_per_utt = (bg.uniform_frames + 3) / 4;
         P.total_groups = P.groups_per_utt * bg.n_utt;
@@ -615,26 +615,32 @@ static int fast1536_launch_t(F1536Params P, const void* d_wave, int dtype, const
         return fast1536_launch_k<NI, NC, NSTAGE, DSP_WAVE_F32, false>(P, d_wave, bg, d_out, ld_out, P.total_groups, st);
     }
     const int64_t bound = bg.total_frames / 4 + bg.n_utt;  // >= sum ceil(T_b / 4)
-    const size_t ws_bytes = ((size_t)bg.n_utt + 1 + (size_t)bound) * sizeof(int32_t);
-    DspWorkspace* w = dsp_workspace_pool().acquire(ws_bytes);
-    if (!w) return DSP_EHIP;
-    int32_t* group_off = static_cast<int32_t*>(w->ptr);
-    int32_t* group_utt = group_off + bg.n_utt + 1;
-    f512_build_group_tables(bg.frame_off, bg.n_utt, 2, group_off, group_utt, st);
-    P.group_off = group_off;
-    P.group_utt = group_utt;
+    DspWorkspace* w = nullptr;
+    if (pre != nullptr && pre->shift == 2) {
+        P.group_off = pre->group_off;
+        P.group_utt = pre->group_utt;
+    } else {
+        const size_t ws_bytes = ((size_t)bg.n_utt + 1 + (size_t)bound) * sizeof(int32_t);
+        w = dsp_workspace_pool().acquire(ws_bytes);
+        if (!w) return DSP_EHIP;
+        int32_t* group_off = static_cast<int32_t*>(w->ptr);
+        int32_t* group_utt = group_off + bg.n_utt + 1;
+        f512_build_group_tables(bg.frame_off, bg.n_utt, 2, group_off, group_utt, st);
+        P.group_off = group_off;
+        P.group_utt = group_utt;
+    }
     int rc;
     if (dtype == DSP_WAVE_I16)
         rc = fast1536_launch_k<NI, NC, NSTAGE, DSP_WAVE_I16, true>(P, d_wave, bg, d_out, ld_out, bound, st);
     else
         rc = fast1536_launch_k<NI, NC, NSTAGE, DSP_WAVE_F32, true>(P, d_wave, bg, d_out, ld_out, bound, st);
-    if (dsp_workspace_pool().release(w, st) != 0 && rc == DSP_OK) rc = DSP_EHIP;
+    if (w != nullptr && dsp_workspace_pool().release(w, st) != 0 && rc == DSP_OK) rc = DSP_EHIP;
     return rc;
 }
 
 static inline int fast1536_launch(const dsp_plan* p, const void* d_wave, int dtype, const BatchGeom& bg,
-                                  float* d_out, int64_t ld_out, hipStream_t st) {
+                                  float* d_out, int64_t ld_out, hipStream_t st, const DspRaggedTables* pre = nullptr) {
     const Fast1536Plan* fp = static_cast<const Fast1536Plan*>(p->d_fast1536);
-    if (fp->variant == 0) return fast1536_launch_t<2, 13, 12>(fp->P, d_wave, dtype, bg, d_out, ld_out, st);
-    return fast1536_launch_t<4, 16, 16>(fp->P, d_wave, dtype, bg, d_out, ld_out, st);
+    if (fp->variant == 0) return fast1536_launch_t<2, 13, 12>(fp->P, d_wave, dtype, bg, d_out, ld_out, st, pre);
+    return fast1536_launch_t<4, 16, 16>(fp->P, d_wave, dtype, bg, d_out, ld_out, st, pre);
 }

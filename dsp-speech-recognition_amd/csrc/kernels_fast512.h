@@ -165,6 +165,21 @@ __device__ __forceinline__ F512Raw<DTYPE> f512_load_raw(const void* __restrict__
     else r.v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(wave) + idx);
     return r;
 }
+// same, from any element address (4-byte / 2-byte aligned): interior groups of ragged batches
+typedef float f512_f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef short f512_s4u __attribute__((ext_vector_type(4), aligned(2)));
+template <int DTYPE>
+__device__ __forceinline__ F512Raw<DTYPE> f512_load_raw_unaligned(const void* __restrict__ wave, int64_t idx) {
+    F512Raw<DTYPE> r;
+    if constexpr (DTYPE == DSP_WAVE_I16) {
+        const f512_s4u t = *reinterpret_cast<const f512_s4u*>(reinterpret_cast<const int16_t*>(wave) + idx);
+        r.v = make_short4(t.x, t.y, t.z, t.w);
+    } else {
+        const f512_f4u t = *reinterpret_cast<const f512_f4u*>(reinterpret_cast<const float*>(wave) + idx);
+        r.v = make_float4(t.x, t.y, t.z, t.w);
+    }
+    return r;
+}
 template <int DTYPE>
 __device__ __forceinline__ void f512_unpack(const F512Raw<DTYPE>& r, float (&x)[4]) {
     x[0] = (float)r.v.x; x[1] = (float)r.v.y; x[2] = (float)r.v.z; x[3] = (float)r.v.w;
@@ -260,20 +275,22 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         (void)utt;
         const int base = t0 * P.S;                            // first sample of the group, utterance relative
         const int64_t g0 = grp.s0 + base;                     // ... in the concatenated buffer
-        const int d = RAGGED ? (int)(g0 & 3) : 0;             // LDS image starts d samples earlier (aligned)
+        // A group that lies entirely inside its utterance (12 of the 13 groups of a 1 s clip) is staged with no
+        // per-vector bookkeeping at all: one base pointer, immediate offsets, no masks.  Ragged batches load
+        // such a group from its first sample as it stands (4-byte aligned vector loads, nothing outside the
+        // utterance is touched), so its LDS image needs no alignment shift either.
+        const bool fast_stage = (NSTAGE * 256 <= F512_WAVE_FLOATS) && base + NSTAGE * 256 <= nsamp;
+        const int d = (RAGGED && !fast_stage) ? (int)(g0 & 3) : 0;   // LDS image starts d samples earlier (aligned)
 
         // ---- stage 7 S + L (+ d) samples: coalesced aligned 16 B loads, all issued before first use;
         //      pre-emphasis, zero fill outside the utterance. ----
-        // Dense batches, group entirely inside its utterance (12 of the 13 groups of a 1 s clip): no
-        // per-vector bookkeeping at all -- one base pointer, immediate offsets, no masks.
-        bool fast_stage = false;
-        if constexpr (!RAGGED && NSTAGE * 256 <= F512_WAVE_FLOATS) fast_stage = base + NSTAGE * 256 <= nsamp;
         if (fast_stage) {
-            if constexpr (!RAGGED) {
+            {
                 F512Raw<DTYPE> raw[NSTAGE];
                 const int64_t e0 = g0 + 4 * lane;
 #pragma unroll
-                for (int r = 0; r < NSTAGE; ++r) raw[r] = f512_load_raw<DTYPE>(wave, e0 + 256 * r);
+                for (int r = 0; r < NSTAGE; ++r)
+                    raw[r] = RAGGED ? f512_load_raw_unaligned<DTYPE>(wave, e0 + 256 * r) : f512_load_raw<DTYPE>(wave, e0 + 256 * r);
                 float left = base > 0 ? dsp_load_sample<DTYPE>(wave, g0 - 1) : 0.f;
 #pragma unroll
                 for (int r = 0; r < NSTAGE; ++r) {
@@ -605,36 +622,56 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
 // utterance of every group.  Both are tiny next to the main kernel and run on the same stream.
 __global__ __launch_bounds__(1024) void f512_group_prefix_kernel(const int64_t* __restrict__ frame_off, int32_t n_utt,
                                                                  int32_t shift, int32_t* __restrict__ group_off,
-                                                                 int32_t* __restrict__ group_utt = nullptr) {
+                                                                 int32_t* __restrict__ group_utt = nullptr,
+                                                                 int32_t tile_shift = 0,
+                                                                 int64_t* __restrict__ tile_off = nullptr) {
+    // optional second table in the same launch: tile_off[b] = sum_{i<b} ceil(T_i / 2^tile_shift) (the delta pass)
     __shared__ int32_t part[1024];
+    __shared__ int32_t part_t[1024];
     const int tid = threadIdx.x;
     const int per = (n_utt + 1023) / 1024;
     const int lo = tid * per, hi = min(lo + per, n_utt);
-    const int64_t rnd = ((int64_t)1 << shift) - 1;
-    int32_t sum = 0;
-    for (int b = lo; b < hi; ++b) sum += (int32_t)((frame_off[b + 1] - frame_off[b] + rnd) >> shift);
+    const int64_t rnd = ((int64_t)1 << shift) - 1, rnd_t = ((int64_t)1 << tile_shift) - 1;
+    int32_t sum = 0, sum_t = 0;
+    for (int b = lo; b < hi; ++b) {
+        const int64_t T = frame_off[b + 1] - frame_off[b];
+        sum += (int32_t)((T + rnd) >> shift);
+        sum_t += (int32_t)((T + rnd_t) >> tile_shift);
+    }
     part[tid] = sum;
+    part_t[tid] = sum_t;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan of the per-thread sums
-        const int32_t v = tid >= off ? part[tid - off] : 0;
+        const int32_t v = tid >= off ? part[tid - off] : 0, vt = tid >= off ? part_t[tid - off] : 0;
         __syncthreads();
         part[tid] += v;
+        part_t[tid] += vt;
         __syncthreads();
     }
     int32_t run = part[tid] - sum;
+    int64_t run_t = part_t[tid] - sum_t;
     for (int b = lo; b < hi; ++b) {
         group_off[b] = run;
-        const int32_t n = (int32_t)((frame_off[b + 1] - frame_off[b] + rnd) >> shift);
+        const int64_t T = frame_off[b + 1] - frame_off[b];
+        const int32_t n = (int32_t)((T + rnd) >> shift);
         if (group_utt != nullptr)   // small batches: fill the group -> utterance table in the same launch
             for (int32_t g = 0; g < n; ++g) group_utt[run + g] = b;
         run += n;
+        if (tile_off != nullptr) {
+            tile_off[b] = run_t;
+            run_t += (T + rnd_t) >> tile_shift;
+        }
     }
-    if (tid == 1023) group_off[n_utt] = part[1023];
+    if (tid == 1023) {
+        group_off[n_utt] = part[1023];
+        if (tile_off != nullptr) tile_off[n_utt] = part_t[1023];
+    }
 }
 
 // Builds both ragged index tables on `st`: one launch for small batches, prefix + parallel fill otherwise.
 static inline void f512_build_group_tables(const int64_t* frame_off, int32_t n_utt, int32_t shift,
-                                           int32_t* group_off, int32_t* group_utt, hipStream_t st);
+                                           int32_t* group_off, int32_t* group_utt, hipStream_t st,
+                                           int64_t* tile_off = nullptr);
 
 __global__ __launch_bounds__(256) void f512_group_fill_kernel(const int32_t* __restrict__ group_off, int32_t n_utt,
                                                               int32_t* __restrict__ group_utt) {
@@ -643,12 +680,13 @@ __global__ __launch_bounds__(256) void f512_group_fill_kernel(const int32_t* __r
 }
 
 static inline void f512_build_group_tables(const int64_t* frame_off, int32_t n_utt, int32_t shift,
-                                           int32_t* group_off, int32_t* group_utt, hipStream_t st) {
+                                           int32_t* group_off, int32_t* group_utt, hipStream_t st,
+                                           int64_t* tile_off) {
     if (n_utt <= 4096) {
-        f512_group_prefix_kernel<<<1, 1024, 0, st>>>(frame_off, n_utt, shift, group_off, group_utt);
+        f512_group_prefix_kernel<<<1, 1024, 0, st>>>(frame_off, n_utt, shift, group_off, group_utt, 7, tile_off);
         return;
     }
-    f512_group_prefix_kernel<<<1, 1024, 0, st>>>(frame_off, n_utt, shift, group_off);
+    f512_group_prefix_kernel<<<1, 1024, 0, st>>>(frame_off, n_utt, shift, group_off, nullptr, 7, tile_off);
     const int fill_blocks = (int)((n_utt + 255) / 256 < 1024 ? (n_utt + 255) / 256 : 1024);
     f512_group_fill_kernel<<<fill_blocks, 256, 0, st>>>(group_off, n_utt, group_utt);
 }
@@ -808,9 +846,16 @@ static int fast512_launch_k(const F512Params& P, const void* d_wave, const Batch
     return hipGetLastError() == hipSuccess ? DSP_OK : DSP_EHIP;
 }
 
+// Ragged index tables built by the caller in one launch together with its own (dsp_mfcc_delta_batch).
+struct DspRaggedTables {
+    int32_t* group_off = nullptr;   // [n_utt + 1] prefix of ceil(T_b / 2^shift)
+    int32_t* group_utt = nullptr;   // utterance of every group
+    int shift = 0;                  // 3: NFFT=512 kernel (8 frames per wave), 2: NFFT=1536 kernel
+};
+
 template <int NROWS, int NI, int NC, int NSTAGE>
 static int fast512_launch_t(F512Params P, const void* d_wave, int dtype, const BatchGeom& bg, float* d_out,
-                            int64_t ld_out, hipStream_t st) {
+                            int64_t ld_out, hipStream_t st, const DspRaggedTables* pre = nullptr) {
     if (bg.uniform_samples > 0) {
         P.groups_per_utt = (bg.uniform_frames + 7) / 8;
         P.total_groups = P.groups_per_utt * bg.n_utt;
@@ -820,28 +865,34 @@ static int fast512_launch_t(F512Params P, const void* d_wave, int dtype, const B
     }
     // ragged: build the group tables in a pooled, event-guarded workspace (no host sync)
     const int64_t bound = bg.total_frames / 8 + bg.n_utt;  // >= sum ceil(T_b / 8)
-    const size_t ws_bytes = ((size_t)bg.n_utt + 1 + (size_t)bound) * sizeof(int32_t);
-    DspWorkspace* w = dsp_workspace_pool().acquire(ws_bytes);
-    if (!w) return DSP_EHIP;
-    int32_t* group_off = static_cast<int32_t*>(w->ptr);
-    int32_t* group_utt = group_off + bg.n_utt + 1;
-    f512_build_group_tables(bg.frame_off, bg.n_utt, 3, group_off, group_utt, st);
-    P.group_off = group_off;
-    P.group_utt = group_utt;
+    DspWorkspace* w = nullptr;
+    if (pre != nullptr && pre->shift == 3) {
+        P.group_off = pre->group_off;
+        P.group_utt = pre->group_utt;
+    } else {
+        const size_t ws_bytes = ((size_t)bg.n_utt + 1 + (size_t)bound) * sizeof(int32_t);
+        w = dsp_workspace_pool().acquire(ws_bytes);
+        if (!w) return DSP_EHIP;
+        int32_t* group_off = static_cast<int32_t*>(w->ptr);
+        int32_t* group_utt = group_off + bg.n_utt + 1;
+        f512_build_group_tables(bg.frame_off, bg.n_utt, 3, group_off, group_utt, st);
+        P.group_off = group_off;
+        P.group_utt = group_utt;
+    }
     int rc;
     if (dtype == DSP_WAVE_I16)
         rc = fast512_launch_k<NROWS, NI, NC, NSTAGE, DSP_WAVE_I16, true>(P, d_wave, bg, d_out, ld_out, bound, st);
     else
         rc = fast512_launch_k<NROWS, NI, NC, NSTAGE, DSP_WAVE_F32, true>(P, d_wave, bg, d_out, ld_out, bound, st);
-    if (dsp_workspace_pool().release(w, st) != 0 && rc == DSP_OK) rc = DSP_EHIP;
+    if (w != nullptr && dsp_workspace_pool().release(w, st) != 0 && rc == DSP_OK) rc = DSP_EHIP;
     return rc;
 }
 
 static inline int fast512_launch(const dsp_plan* p, const void* d_wave, int dtype, const BatchGeom& bg,
-                                 float* d_out, int64_t ld_out, hipStream_t st) {
+                                 float* d_out, int64_t ld_out, hipStream_t st, const DspRaggedTables* pre = nullptr) {
     const Fast512Plan* fp = static_cast<const Fast512Plan*>(p->d_fast);
     // exact instantiations for the common shapes, a padded catch-all otherwise (chosen at plan init)
-    if (fp->variant == 0) return fast512_launch_t<25, 4, 13, 6>(fp->P, d_wave, dtype, bg, d_out, ld_out, st);
-    if (fp->variant == 1) return fast512_launch_t<25, 5, 13, 6>(fp->P, d_wave, dtype, bg, d_out, ld_out, st);
-    return fast512_launch_t<32, 8, 16, 9>(fp->P, d_wave, dtype, bg, d_out, ld_out, st);
+    if (fp->variant == 0) return fast512_launch_t<25, 4, 13, 6>(fp->P, d_wave, dtype, bg, d_out, ld_out, st, pre);
+    if (fp->variant == 1) return fast512_launch_t<25, 5, 13, 6>(fp->P, d_wave, dtype, bg, d_out, ld_out, st, pre);
+    return fast512_launch_t<32, 8, 16, 9>(fp->P, d_wave, dtype, bg, d_out, ld_out, st, pre);
 }

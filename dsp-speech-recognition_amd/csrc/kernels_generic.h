@@ -352,12 +352,21 @@ __global__ __launch_bounds__(256) void delta_rows_kernel(const float* __restrict
     float* out_u = out + (base + t0) * 3 * D;
     float* sx = smem_d;                           // [rows_x][D]  x[clamp(t0 - 2N + r)]
     float* sd = smem_d + (DT_TILE + 4 * N) * D;   // [rows_d][D]  delta[clamp(t0 - N + r)]
-    // interior rows are one contiguous run of the dense input; only the clamped halo rows gather
-    for (int i = threadIdx.x; i < rows_x * D; i += 256) {
-        const int r = i / D, d = i - r * D;
-        int tt = t0 - 2 * N + r;
-        tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
-        sx[i] = in_u[tt * D + d];
+    // all of a thread's loads are issued before the first one is used (eight in flight per thread: the tile
+    // is a few KB, the pass is latency bound otherwise)
+    for (int i0 = threadIdx.x; i0 < rows_x * D; i0 += 8 * 256) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + 256 * k;
+            const int r = i / D, d = i - r * D;
+            int tt = t0 - 2 * N + r;
+            tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
+            v[k] = i < rows_x * D ? in_u[tt * D + d] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (i0 + 256 * k < rows_x * D) sx[i0 + 256 * k] = v[k];
     }
     __syncthreads();
     for (int i = threadIdx.x; i < rows_d * D; i += 256) {
