@@ -229,7 +229,17 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mfcc1536_kernel(F1536Params P, 
     const int total_groups = RAGGED ? P.group_off[bg.n_utt] : (int)P.total_groups;
     const int gstride = (int)gridDim.x * WAVES;
 
-    for (int G = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WAVES + wid); G < total_groups; G += gstride) {
+    // full rounds deal 8 consecutive groups to the 8 waves of a workgroup; the partial last round is dealt
+    // wave-major (wave 0 of every workgroup first) so that no SIMD carries two groups above the average
+    const int nfull = total_groups / gstride;
+    for (int rnd = 0; rnd <= nfull; ++rnd) {
+        int G;
+        if (rnd < nfull) {
+            G = __builtin_amdgcn_readfirstlane(rnd * gstride + (int)blockIdx.x * WAVES + wid);
+        } else {
+            G = __builtin_amdgcn_readfirstlane(nfull * gstride + (int)blockIdx.x + (int)gridDim.x * wid);
+            if (G >= total_groups) break;
+        }
         int lane = tid & 63;
         asm volatile("" : "+v"(lane));  // keep lane-derived addresses out of loop-invariant registers
         const int f = lane >> 4, c = lane & 15;
@@ -237,10 +247,33 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mfcc1536_kernel(F1536Params P, 
         const int t0 = grp.t0, T = grp.T, nsamp = grp.nsamp;
         const int base = t0 * P.S;
         const int64_t g0 = grp.s0 + base;
-        const int d = RAGGED ? (int)(g0 & 3) : 0;
+        // groups entirely inside their utterance stage without per-vector bookkeeping (kernels_fast512.h)
+        const bool fast_stage = base + NSTAGE * 256 <= nsamp;
+        const int d = (RAGGED && !fast_stage) ? (int)(g0 & 3) : 0;
 
-        // ---- stage 3 S + 1536 (+ d) samples: aligned 16 B loads, pre-emphasis, zero fill ----
-        {
+        // ---- stage 3 S + 1536 (+ d) samples: 16 B loads, pre-emphasis, zero fill ----
+        if (fast_stage) {
+            F512Raw<DTYPE> raw[NSTAGE];
+            const int64_t e0 = g0 + 4 * lane;
+#pragma unroll
+            for (int r = 0; r < NSTAGE; ++r)
+                raw[r] = RAGGED ? f512_load_raw_unaligned<DTYPE>(wave, e0 + 256 * r) : f512_load_raw<DTYPE>(wave, e0 + 256 * r);
+            float left = base > 0 ? dsp_load_sample<DTYPE>(wave, g0 - 1) : 0.f;
+            const int span_vec = P.span_vec;
+#pragma unroll
+            for (int r = 0; r < NSTAGE; ++r) {
+                float x[4];
+                f512_unpack<DTYPE>(raw[r], x);
+                const float prev = f512_shift_in(x[3], left);
+                left = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[3]), 63));
+                float4 y;
+                y.x = fmaf(-P.preemph, prev, x[0]);
+                y.y = fmaf(-P.preemph, x[0], x[1]);
+                y.z = fmaf(-P.preemph, x[1], x[2]);
+                y.w = fmaf(-P.preemph, x[2], x[3]);
+                if (lane + 64 * r < span_vec) *reinterpret_cast<float4*>(wbuf + 4 * lane + 256 * r) = y;
+            }
+        } else {
             const int64_t a0 = g0 - d;
             const int span_vec = RAGGED ? P.span_vec + 1 : P.span_vec;
             F512Raw<DTYPE> raw[NSTAGE];
@@ -591,12 +624,9 @@ template <int NI, int NC, int NSTAGE, int DTYPE, bool RAGGED>
 static int fast1536_launch_k(const F1536Params& P, const void* d_wave, const BatchGeom& bg, float* d_out,
                              int64_t ld_out, int64_t groups_bound, hipStream_t st) {
     const size_t lds = ((size_t)P.tab_floats + (size_t)F1536_WAVES * P.wave_floats) * sizeof(float);
-    const int64_t cap = 256;  // one 8-wave workgroup per CU (LDS bound)
+    const int64_t cap = 256;  // one 8-wave workgroup per CU (LDS bound); the kernel deals the partial last round
     int64_t blocks = (groups_bound + F1536_WAVES - 1) / F1536_WAVES;
-    if (blocks > cap) {
-        const int64_t rounds = (blocks + cap - 1) / cap;
-        blocks = (blocks + rounds - 1) / rounds;
-    }
+    if (blocks > cap) blocks = cap;
     auto k = mfcc1536_kernel<NI, NC, NSTAGE, DTYPE, F1536_WAVES, RAGGED>;
     static size_t granted[DSP_MAX_DEVICES] = {};
     if (dsp_ensure_dynamic_lds((const void*)k, lds, granted) != 0) return DSP_EHIP;
