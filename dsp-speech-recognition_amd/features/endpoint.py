@@ -132,6 +132,23 @@ def zcr_rule(zcr, left, right, max_shift=0.400, l_sil=0, r_sil=0.100):
     return j, k
 
 
+def get_noise(amp, sep_point):
+    """Mean frame amplitude outside the detected segments (endpoint.py:94-107); when the rule fell back
+    to the whole clip there is no outside and the reference answers 1e30."""
+    amp = np.asarray(amp, dtype=np.float64)
+    segs = [(int(a), int(b)) for a, b in sep_point]
+    if segs[0] == (0, len(amp)):
+        return 1e30
+    total, count, left = 0.0, 0, 0
+    for lo, hi in segs:
+        total += float(np.sum(amp[left:lo]))
+        count += lo - left
+        left = hi
+    total += float(np.sum(amp[left:]))
+    count += len(amp) - left
+    return total / count
+
+
 def basic_endpoint_detection(sig, rate, return_feature=False):
     """Energy + ZCR endpointing (endpoint.py:34-66) -> (left_sample, right_sample[, amp, zcr]).
     Framing (cfg.frame / cfg.step, int()-truncated sizes), amplitude, ZCR and the rule all run on

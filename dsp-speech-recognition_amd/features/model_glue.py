@@ -14,10 +14,18 @@ from .base import delta, mfcc
 from . import endpoint as _endpoint
 
 
-def endpoint_detect(sig, rate):
-    """model.py:52-64 without augmentation: trim to the detected endpoints and divide by the
-    population standard deviation (sklearn ``scale(with_mean=False)``; a zero std divides by 1)."""
+def endpoint_detect(sig, rate, augment=False, rng=None):
+    """model.py:52-64: trim to the detected endpoints (with augment=True widened by two draws of
+    randint(0, int(0.1 * rate)) from ``rng`` -- a ``random.Random``, default the global generator the
+    reference uses) and divide by the population standard deviation (sklearn
+    ``scale(with_mean=False)``; a zero std divides by 1)."""
     left, right = _endpoint.basic_endpoint_detection(sig, rate)
+    if augment:
+        import random
+        gen = rng if rng is not None else random
+        hi = int(0.1 * rate)
+        s_l, s_r = gen.randint(0, hi), gen.randint(0, hi)
+        left, right = max(left - s_l, 0), max(right + s_r, 0)
     clip = np.asarray(sig[left:right], dtype=np.float64).reshape(-1, 1)
     sd = clip.std(axis=0)
     sd[sd == 0.0] = 1.0
@@ -73,10 +81,17 @@ def pad200(b):
     return np.array(b[:200])
 
 
-def model_pipeline(sig, rate):
+def model_pipeline(sig, rate, augment=False, rng=None):
     """Raw int16 clip -> ((mfcc0, mfcc1, mfcc2), n) exactly as RNNModel.get_batch_full feeds the
-    classifier per utterance (model.py:113-124, augment=False)."""
-    return feature_extract_mfcc(endpoint_detect(sig, rate), rate)
+    classifier per utterance (model.py:113-124; augment=True is the training call of model.py:144)."""
+    return feature_extract_mfcc(endpoint_detect(sig, rate, augment=augment, rng=rng), rate)
+
+
+def model_pipeline_aug(sig, rate, seed):
+    """The training path with the jitter drawn from ``random.Random(seed)`` (test hook: what the
+    reference computes after ``random.seed(seed)``)."""
+    import random
+    return model_pipeline(sig, rate, augment=True, rng=random.Random(seed))
 
 
 def batch_to_rnn_input(features, frame_offsets, max_len=200):

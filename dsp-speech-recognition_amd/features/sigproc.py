@@ -111,6 +111,14 @@ def deframesig(frames, siglen, frame_len, frame_step, winfunc=_ones):
     return (rec / corr)[:siglen]
 
 
+def rolling_window(a, window, step=1):
+    """All length-``window`` runs along the last axis, every ``step``-th one (sigproc.py:59-63; the
+    reference builds them as a strided view, here they are gathered -- same values, fresh array)."""
+    a = numpy.asarray(a)
+    starts = numpy.arange(0, a.shape[-1] - window + 1, step)
+    return a[..., starts[:, None] + numpy.arange(window)[None, :]]
+
+
 def acr(frame, n):
     """Autocorrelation at lag n divided by the overlap length (sigproc.py:48-53); host scalar
     helper of the pitch / robust-endpoint code, off the hot path."""

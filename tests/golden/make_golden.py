@@ -37,7 +37,7 @@ def load_reference():
                  'deframesig', 'get_filterbanks', 'fbank', 'mfcc', 'lifter', 'delta',
                  'get_amplitude', 'get_zcr', 'amplitude_rule', 'zcr_rule', 'amplitude_feature',
                  'basic_endpoint_detection', 'robust_endpoint_detection', 'downsampling', 'center_clip',
-                 'pitch_detect_frame_sr', 'pitch_detect_sr'):
+                 'pitch_detect_frame_sr', 'pitch_detect_sr', 'get_noise', 'rolling_window'):
         setattr(api, name, getattr(features, name))
     # NOTE: ``features.preemphasis`` resolves to preprocess.preemphasis (star-import order); the
     # sigproc one is what fbank calls.  They are identical; record the sigproc one.
@@ -49,6 +49,15 @@ def load_reference():
         return base.feature_extract_mfcc(None, sound, rate)
 
     api.model_pipeline = model_pipeline
+
+    def model_pipeline_aug(sig, rate, seed):
+        import random
+        random.seed(seed)                      # model.py:55 draws from the global generator
+        base = model._ModelBase
+        sound = base.endpoint_detect(None, sig, rate, augment=True)
+        return base.feature_extract_mfcc(None, sound, rate)
+
+    api.model_pipeline_aug = model_pipeline_aug
     bare = object.__new__(model._ModelBase)            # the methods only use self.deviation
     api.model_feature_extract_pitch = bare.feature_extract_pitch
     api.model_feature_extract_timespace = bare.feature_extract_timespace

@@ -189,6 +189,16 @@ _add('pitch_sr_harm', 'pitch_detect_sr', ('harmonic', 97, 12000), rate=16000, wi
 # model.py:90-101: the optional pitch / amplitude streams (cfg.use_pitch, cfg.use_timefeat)
 _add('model_side_streams', 'model_side_streams', ('vadf', 98, 24000), rate=16000)
 
+# training path of model.py:52-64: endpoint jitter (augment=True) drawn from Python's global `random`, seeded
+_add('model_feat_jitter_44k', 'model_feature_extract_mfcc_aug', ('vad', 75, 52920, 44100, 0.6), rate=44100, seed=1234)
+_add('model_feat_jitter_16k', 'model_feature_extract_mfcc_aug', ('vad', 76, 28000, 16000, 0.7), rate=16000, seed=7)
+
+# surface crumbs: endpoint.get_noise (endpoint.py:94-107), sigproc.rolling_window (sigproc.py:59-63)
+_add('get_noise_bursts', 'get_noise', ('bursts', 55, 32000), mh=0.25)
+_add('get_noise_whole', 'get_noise', ('int16', 56, 16000), mh=0.25)
+_add('rolling_window', 'rolling_window', ('ramp', 81, 50), window=7, step=3)
+_add('rolling_window_1', 'rolling_window', ('white', 82, 20), window=20, step=1)
+
 # deframesig (API-surface extra)
 _add('deframesig', 'deframesig', ('white', 80, 2000), frame_len=400, frame_step=160,
      winfunc='hamming')
@@ -274,6 +284,16 @@ def run_case(case, api):
         (m0, m1, m2), n = api.model_pipeline(x, kw['rate'])
         return {'m0': np.asarray(m0), 'm1': np.asarray(m1), 'm2': np.asarray(m2),
                 'len': np.array([n], dtype=np.int64)}
+    if fn == 'model_feature_extract_mfcc_aug':
+        (m0, m1, m2), n = api.model_pipeline_aug(x, kw['rate'], kw['seed'])
+        return {'m0': np.asarray(m0), 'm1': np.asarray(m1), 'm2': np.asarray(m2),
+                'len': np.array([n], dtype=np.int64)}
+    if fn == 'get_noise':
+        amp = api.get_amplitude(api.to_frames(x, 16000, t=0.03, step=0.01))
+        seg = api.amplitude_rule(amp, **kw)
+        return {'out': np.array([api.get_noise(amp, seg)], dtype=np.float64)}
+    if fn == 'rolling_window':
+        return {'out': np.array(api.rolling_window(np.asarray(x, dtype=np.float64), **kw))}
     if fn == 'pitch_detect_sr':
         down = np.asarray(api.downsampling(x, kw['rate'], 10000))
         frames = api.to_frames(down, 10000, kw['winlen'], kw['step'])

@@ -37,11 +37,13 @@ def api():
                  'get_filterbanks', 'fbank', 'mfcc', 'lifter', 'delta', 'get_amplitude', 'get_zcr',
                  'amplitude_rule', 'zcr_rule', 'amplitude_feature', 'basic_endpoint_detection',
                  'robust_endpoint_detection', 'downsampling', 'center_clip', 'pitch_detect_frame_sr',
-                 'pitch_detect_sr'):
+                 'pitch_detect_sr', 'get_noise', 'rolling_window'):
         setattr(a, name, getattr(features, name))
     a.preemphasis = features.sigproc.preemphasis
-    from features.model_glue import feature_extract_pitch, feature_extract_timespace, model_pipeline
+    from features.model_glue import (feature_extract_pitch, feature_extract_timespace, model_pipeline,
+                                     model_pipeline_aug)
     a.model_pipeline = model_pipeline
+    a.model_pipeline_aug = model_pipeline_aug
     a.model_feature_extract_pitch = feature_extract_pitch
     a.model_feature_extract_timespace = feature_extract_timespace
     return a
@@ -73,7 +75,7 @@ def test_gpu_matches_reference(case, golden, api):
             assert np.max(np.abs(val)) <= 1e-5, (case['name'], key, np.max(np.abs(val)))
             continue
         err = normwise(val, ref)
-        is_m0 = case['fn'] == 'model_feature_extract_mfcc' and key == 'm0'
+        is_m0 = case['fn'].startswith('model_feature_extract_mfcc') and key == 'm0'
         from conftest import record
         record('golden_model_m0' if is_m0 else 'golden_float_outputs', err)
         tol = M0_TOL if is_m0 else TOL

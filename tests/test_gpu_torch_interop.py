@@ -272,3 +272,36 @@ def test_dense_step_is_hip_graph_capturable():
         g.replay()
         torch.cuda.synchronize(dev)
         assert torch.equal(out, eager)
+
+
+def test_model_feature_batch_training_path_with_jitter(golden):
+    """model.py:144 calls get_batch_full(augment=True): the endpoint jitter of model.py:54-60, batched on
+    the device (host-drawn offsets -> dsp_endpoint_layout_batch), against outputs of the REAL reference run
+    after random.seed(k) -- utterance 0 and 1 are the two golden cases, drawn in the reference's order."""
+    import random
+    from features.model_glue import ModelFeatureBatch
+    from golden_cases import make_signal, case_by_name
+    from conftest import normwise, record
+    case = case_by_name('model_feat_jitter_44k')
+    clip = make_signal(case['sig'])
+    mfb = ModelFeatureBatch(rate=44100)
+    jit = mfb.draw_jitter(1, random.Random(case['kw']['seed']))
+    assert jit[0, 0] <= 0 <= jit[0, 1]
+    other = make_signal(('vad', 77, 50000, 44100, 0.5))
+    clips = [clip, other]
+    so = np.concatenate(([0], np.cumsum([len(c) for c in clips]))).astype(np.int64)
+    jit2 = np.concatenate([jit, [[-1234, 4321]]]).astype(np.int64)
+    inp, len0, ends = mfb.run(np.concatenate(clips), so, jitter=jit2)
+    got = inp.cpu().numpy()
+    for key, col in (('m0', 0), ('m1', 13), ('m2', 26)):
+        ref = golden[f'model_feat_jitter_44k/{key}']
+        n = min(len(ref), 200)
+        assert len0[0] == n == int(golden['model_feat_jitter_44k/len'][0])
+        err = record('model_batch_jitter_' + key, normwise(got[:n, 0, col:col + 13], ref[:n]))
+        assert err <= 1e-4, (key, err)
+    (m0, m1, m2), n = dsp_oracle.model_pipeline(other, 44100, jitter=(1234, 4321))
+    ref = np.concatenate([m0, m1, m2], axis=1)[:n]
+    assert len0[1] == n and normwise(got[:n, 1], ref) <= 1e-4
+    # augment=False of the same object: the jitter really moved the endpoints
+    _, _, ends0 = mfb.run(np.concatenate(clips), so)
+    assert ends0[0, 0] - ends[0, 0] == -jit[0, 0] or ends[0, 0] == 0
