@@ -10,6 +10,8 @@
 // of a wave instruction hit disjoint LDS banks whatever the hop is.  fp64 accumulation.
 #pragma once
 
+#include <type_traits>
+
 #include "kernels_fast512.h"
 
 #define VAD_NSTAGE 12   // 12 x 64 lanes x 4 samples staged per wave at most
@@ -276,6 +278,143 @@ __global__ __launch_bounds__(64 * VAD_WAVES) void vad_vec_kernel(VadParams P, Ba
     }
 }
 
+// Vector-aligned frames (L % 4 == 0 and S % 4 == 0 -- every framing the endpoint path uses at 16 / 44.1 /
+// 48 kHz): the wave loads its samples from the group's FIRST sample as it stands (vector loads at the
+// element's own alignment), so every frame is a whole number of 4-sample vectors and nothing but two
+// numbers per vector has to be staged: a4 = sum of |x| (or x^2) over the vector and the sign-change bits
+// of its four (i - 1, i) pairs.  Every sample is visited once, for int16 AND fp32 input (SURVEY 8a-12/13:
+// endpoint.py:109-126, 182-198); 8 bytes (12 with fp64 sums) of LDS per vector instead of 24, so three
+// times as many waves fit a CU as with vad_vec_kernel.  A frame = its L / 4 vector totals; its count
+// drops the first vector's pair (s - 1, s), which lies outside the frame.
+//   sums: fp32 when exact (int16 input, |x|: a lane's partial stays below 2^24), fp64 otherwise.
+template <int DTYPE, int FR, bool RAGGED, bool F32SUM>
+__global__ __launch_bounds__(64 * VAD_WAVES) void vad_sum_kernel(VadParams P, BatchGeom bg,
+                                                                 const void* __restrict__ wave,
+                                                                 double* __restrict__ amp_sum,
+                                                                 int32_t* __restrict__ zcr) {
+    using acc_t = typename std::conditional<F32SUM, float, double>::type;
+    constexpr int LPF = 64 / FR;
+    constexpr int SHIFT = FR == 16 ? 4 : 2;
+    extern __shared__ __attribute__((aligned(256))) float smem_f[];
+    const int tid = threadIdx.x;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    // per-wave region: nvec sums (acc_t) followed by nvec int32 bit words
+    char* wb = reinterpret_cast<char*>(smem_f) + (size_t)wid * P.wave_floats * 4;
+    acc_t* a4s = reinterpret_cast<acc_t*>(wb);
+    int32_t* es = reinterpret_cast<int32_t*>(wb + (size_t)P.off_e * 4);
+    const int total_groups = RAGGED ? P.group_off[bg.n_utt] : (int)P.total_groups;
+    const int gstride = (int)gridDim.x * VAD_WAVES;
+    const int f = lane / LPF, q = lane % LPF;
+    const int vpf = P.L >> 2, vps = P.S >> 2;      // vectors per frame / per hop
+    const int nvec = P.span_vec;                    // (FR - 1) S / 4 + L / 4
+
+    for (int G = __builtin_amdgcn_readfirstlane((int)blockIdx.x * VAD_WAVES + wid); G < total_groups; G += gstride) {
+        int utt, t0, T, nsamp;
+        int64_t s0, row0;
+        if constexpr (RAGGED) {
+            utt = P.group_utt[G];
+            t0 = (G - P.group_off[utt]) << SHIFT;
+            s0 = bg.sample_off[utt];
+            nsamp = (int)(bg.sample_off[utt + 1] - s0);
+            row0 = bg.frame_off[utt];
+            T = (int)(bg.frame_off[utt + 1] - row0);
+        } else {
+            const int gpu = (int)P.groups_per_utt;
+            utt = G / gpu;
+            t0 = (G - utt * gpu) << SHIFT;
+            nsamp = (int)bg.uniform_samples;
+            T = (int)bg.uniform_frames;
+            s0 = (int64_t)utt * bg.uniform_samples;
+            row0 = (int64_t)utt * bg.uniform_frames;
+        }
+        const int base = t0 * P.S;
+        const int64_t g0 = s0 + base;
+        // ---- one pass over the samples: all loads first, then sums and pair bits ----
+        F512Raw<DTYPE> raw[VAD_NSTAGE];
+#pragma unroll
+        for (int r = 0; r < VAD_NSTAGE; ++r) {
+            const int v = lane + 64 * r;
+            const int rel = base + 4 * v;
+            if (v < nvec && rel + 3 < nsamp) {
+                raw[r] = f512_load_raw_unaligned<DTYPE>(wave, g0 + 4 * v);       // entirely inside the clip
+            } else {                                                              // clip end: element by element
+                float e[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e[k] = (v < nvec && rel + k < nsamp) ? dsp_load_sample<DTYPE>(wave, g0 + 4 * v + k) : 0.f;
+                if constexpr (DTYPE == DSP_WAVE_I16) raw[r].v = make_short4((short)e[0], (short)e[1], (short)e[2], (short)e[3]);
+                else raw[r].v = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        }
+        float left = 0.f;   // the pair (first staged sample - 1, first staged sample) is never inside a frame
+#pragma unroll
+        for (int r = 0; r < VAD_NSTAGE; ++r) {
+            const int v = lane + 64 * r;
+            float x[4];
+            f512_unpack<DTYPE>(raw[r], x);
+            const float prev = f512_shift_in(x[3], left);
+            left = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[3]), 63));
+            uint32_t b0, b1, b2, b3;
+            if constexpr (DTYPE == DSP_WAVE_I16) {
+                // int16 products cannot underflow: x[i-1] * x[i] < 0 is the exact sign-pair test
+                b0 = prev * x[0] < 0.f; b1 = x[0] * x[1] < 0.f; b2 = x[1] * x[2] < 0.f; b3 = x[2] * x[3] < 0.f;
+            } else {
+                // fp32: opposite sign bits and both non-zero (a product could underflow to 0)
+                auto opp = [](float a, float b) -> uint32_t {
+                    return ((__float_as_uint(a) ^ __float_as_uint(b)) >> 31) & (uint32_t)(a != 0.f) & (uint32_t)(b != 0.f);
+                };
+                b0 = opp(prev, x[0]); b1 = opp(x[0], x[1]); b2 = opp(x[1], x[2]); b3 = opp(x[2], x[3]);
+            }
+            acc_t a4;
+            if (P.use_sq) {
+                a4 = ((acc_t)x[0] * (acc_t)x[0] + (acc_t)x[1] * (acc_t)x[1]) + ((acc_t)x[2] * (acc_t)x[2] + (acc_t)x[3] * (acc_t)x[3]);
+            } else {
+                a4 = ((acc_t)fabsf(x[0]) + (acc_t)fabsf(x[1])) + ((acc_t)fabsf(x[2]) + (acc_t)fabsf(x[3]));
+            }
+            if (v < nvec) {
+                a4s[v] = a4;
+                es[v] = (int32_t)(b0 | ((b0 + b1 + b2 + b3) << 8));
+            }
+        }
+        F512_FENCE();
+
+        // ---- frame f = vectors [f vps, f vps + vpf); lane q takes every LPF-th of them ----
+        const int v_lo = f * vps, v_hi = v_lo + vpf;
+        acc_t acc = 0;
+        int32_t cnt = 0;
+        for (int v0 = v_lo + q; v0 < v_hi; v0 += 8 * LPF) {
+            acc_t av[8];
+            int32_t ev[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int v = min(v0 + u * LPF, v_hi - 1);
+                av[u] = a4s[v];
+                ev[u] = es[v];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool in = v0 + u * LPF < v_hi;
+                acc += in ? av[u] : (acc_t)0;
+                cnt += in ? (ev[u] >> 8) : 0;
+            }
+        }
+        if (q == 0) cnt -= es[v_lo] & 1;        // the pair (s - 1, s) belongs to the previous sample
+        double accd = (double)acc;               // fp32 lane partials are exact integers below 2^24
+#pragma unroll
+        for (int o = LPF / 2; o > 0; o >>= 1) {
+            accd += __shfl_xor(accd, o, 64);
+            cnt += __shfl_xor(cnt, o, 64);
+        }
+        const int t = t0 + f;
+        if (q == 0 && t < T) {
+            amp_sum[row0 + t] = accd;
+            zcr[row0 + t] = cnt;
+        }
+        F512_FENCE();
+    }
+}
+
 // Picks the tile shape; returns 0 if the configuration has to take the one-wave-per-frame kernel.
 static inline int vad_tile_frames(int32_t L, int32_t S) {
     if (L < 64 || S < 1) return 0;
@@ -308,6 +447,36 @@ static int vad_tile_launch_k(const VadParams& P, const BatchGeom& bg, const void
     // int16 samples: the |x| sum of one lane stays below 2^24, so fp32 partial sums are exact
     const bool f32_exact = DTYPE == DSP_WAVE_I16 && !P.use_sq && (P.L + 64 / FR - 1) / (64 / FR) < 512;
     static const bool force_walk = getenv("DSP_VAD_WALK") != nullptr;   // A/B aid: keep the per-frame walk
+    static const bool no_sum = getenv("DSP_VAD_NOSUM") != nullptr;       // A/B aid: skip vad_sum_kernel
+    if ((P.L % 4) == 0 && (P.S % 4) == 0 && !force_walk && !no_sum) {
+        // vector-aligned frames: visit-once kernel with 8 (12) bytes of LDS per vector, both input types
+        VadParams Q = P;
+        Q.span_vec = ((FR - 1) * P.S + P.L) / 4;
+        const size_t sum_bytes = f32_exact ? 4 : 8;
+        Q.off_e = (int32_t)((((size_t)Q.span_vec * sum_bytes + 15) / 16 * 16) / 4);       // floats
+        Q.wave_floats = (int32_t)(((size_t)Q.off_e + Q.span_vec + 63) / 64 * 64);
+        if (Q.span_vec <= 64 * VAD_NSTAGE) {
+            const size_t lds3 = (size_t)VAD_WAVES * Q.wave_floats * sizeof(float);
+            int64_t blocks3 = (groups_bound + VAD_WAVES - 1) / VAD_WAVES;
+            int per_cu = (int)((size_t)(150 * 1024) / (lds3 ? lds3 : 1));
+            if (per_cu > 8) per_cu = 8;
+            if (per_cu < 1) per_cu = 1;
+            const int64_t cap3 = 256 * (int64_t)per_cu;
+            if (blocks3 > cap3) blocks3 = cap3;
+            if (f32_exact) {
+                auto k = vad_sum_kernel<DTYPE, FR, RAGGED, true>;
+                static size_t granted[DSP_MAX_DEVICES] = {};
+                if (lds3 > 48 * 1024 && dsp_ensure_dynamic_lds((const void*)k, lds3, granted) != 0) return DSP_EHIP;
+                k<<<(int)blocks3, 64 * VAD_WAVES, lds3, st>>>(Q, bg, d_wave, d_amp, d_zcr);
+            } else {
+                auto k = vad_sum_kernel<DTYPE, FR, RAGGED, false>;
+                static size_t granted[DSP_MAX_DEVICES] = {};
+                if (lds3 > 48 * 1024 && dsp_ensure_dynamic_lds((const void*)k, lds3, granted) != 0) return DSP_EHIP;
+                k<<<(int)blocks3, 64 * VAD_WAVES, lds3, st>>>(Q, bg, d_wave, d_amp, d_zcr);
+            }
+            return hipGetLastError() == hipSuccess ? DSP_OK : DSP_EHIP;
+        }
+    }
     if (f32_exact && !force_walk) {
         // visit-once kernel: samples + per-vector sums + sign bits per wave (6 floats per staged vector)
         VadParams Q = P;
