@@ -550,7 +550,7 @@ __global__ __launch_bounds__(64) void endpoint_rule_kernel(const double* __restr
     __shared__ double s_sil[DSP_MAX_SIL];
     __shared__ double s_sorted[DSP_MAX_SIL];
     __shared__ double s_thr[3];
-    __shared__ uint8_t s_cls[DSP_RULE_LDS_FRAMES];
+    __shared__ unsigned long long s_bits[5][DSP_RULE_LDS_FRAMES / 64];
     const int32_t b = blockIdx.x;
     if (b >= n_utt) return;
     const int64_t base = frame_off[b];
@@ -606,37 +606,77 @@ __global__ __launch_bounds__(64) void endpoint_rule_kernel(const double* __restr
             s_thr[2] = (M_L > a2) ? M_L : a2;
         }
         __syncthreads();
-        // (4) whole wave: every comparison the scans can ask for, one byte per frame
+        // (4) whole wave: every comparison the scans can ask for, as one bit per frame in 64-frame ballot
+        //     words (bits at and beyond T are clear, so "first clear bit" never runs past T)
+        const int words = ((int)T + 63) >> 6;
         {
             const double M_L = s_thr[0], M_H1 = s_thr[1], M_H2 = s_thr[2];
-            for (int i = lane; i < (int)T; i += 64) {
-                const double v = s_amp[i];
-                s_cls[i] = (uint8_t)((v > M_L ? 1 : 0) | (v > M_H1 ? 2 : 0) | (v >= M_H1 ? 4 : 0) |
-                                     (v > M_H2 ? 8 : 0) | (v >= M_H2 ? 16 : 0));
+            for (int w = 0; w < words; ++w) {
+                const int i = 64 * w + lane;
+                const bool ok = i < (int)T;
+                const double v = ok ? s_amp[i] : 0.0;
+                const unsigned long long m0 = __ballot(ok && v > M_L), m1 = __ballot(ok && v > M_H1),
+                                         m2 = __ballot(ok && v >= M_H1), m3 = __ballot(ok && v > M_H2),
+                                         m4 = __ballot(ok && v >= M_H2);
+                if (lane == 0) {
+                    s_bits[0][w] = m0; s_bits[1][w] = m1; s_bits[2][w] = m2; s_bits[3][w] = m3; s_bits[4][w] = m4;
+                }
             }
         }
         __syncthreads();
         if (lane != 0) return;
-        // (5) lane 0: the two-threshold scan (endpoint.py:155-179) on the class bytes
+        // (5) lane 0: the two-threshold scan (endpoint.py:155-179), a word at a time: O(runs), not O(frames)
+        auto next_set = [&](const unsigned long long* m, int64_t i) -> int64_t {     // first set bit at >= i, else T
+            int w = (int)(i >> 6);
+            if (w >= words) return T;
+            unsigned long long x = m[w] & (~0ull << (i & 63));
+            while (x == 0) {
+                if (++w >= words) return T;
+                x = m[w];
+            }
+            return 64 * (int64_t)w + __builtin_ctzll(x);
+        };
+        auto next_clear = [&](const unsigned long long* m, int64_t i) -> int64_t {   // first clear bit at >= i (<= T)
+            int w = (int)(i >> 6);
+            if (w >= words) return T;
+            unsigned long long x = ~m[w] & (~0ull << (i & 63));
+            while (x == 0) {
+                if (++w >= words) return T;
+                x = ~m[w];
+            }
+            const int64_t r = 64 * (int64_t)w + __builtin_ctzll(x);
+            return r < T ? r : T;
+        };
+        auto prev_clear = [&](const unsigned long long* m, int64_t i) -> int64_t {   // last clear bit at <= i, else 0
+            int w = (int)(i >> 6);
+            const int sh = 63 - (int)(i & 63);
+            unsigned long long x = (~m[w] << sh) >> sh;                               // bits 0 .. (i & 63)
+            while (x == 0) {
+                if (--w < 0) return 0;
+                x = ~m[w];
+            }
+            return 64 * (int64_t)w + 63 - __builtin_clzll(x);
+        };
         const double T_H = 0.100 / cfg_frame;
         int64_t left = 0, right = T;
         for (int pass = 0; pass < 2; ++pass) {
-            const uint8_t hi = pass == 0 ? 2 : 8, ge = pass == 0 ? 4 : 16;
+            const unsigned long long* hi = s_bits[pass == 0 ? 1 : 3];
+            const unsigned long long* ge = s_bits[pass == 0 ? 2 : 4];
+            const unsigned long long* ml = s_bits[0];
             bool any = false;
             int64_t i = 0;
             while (i < T) {
-                if (s_cls[i] & ge) {
-                    int64_t j = i, k = i;
-                    while (k < T && (s_cls[k] & hi)) ++k;
-                    if ((double)(k - j) < T_H) {
-                        i = k;
-                    } else {
-                        while (j > 0 && (s_cls[j] & 1)) --j;
-                        while (k < T && (s_cls[k] & 1)) ++k;
-                        if (!any) { left = j; any = true; }
-                        right = k;
-                        i = k;
-                    }
+                i = next_set(ge, i);                      // frames below the entry threshold are stepped over
+                if (i >= T) break;
+                int64_t j = i, k = next_clear(hi, i);     // while (k < T && amp[k] > M_H) ++k
+                if ((double)(k - j) < T_H) {
+                    i = k;
+                } else {
+                    j = prev_clear(ml, j);                // while (j > 0 && amp[j] > M_L) --j
+                    k = next_clear(ml, k);                // while (k < T && amp[k] > M_L) ++k
+                    if (!any) { left = j; any = true; }
+                    right = k;
+                    i = k;
                 }
                 ++i;
             }
@@ -650,9 +690,6 @@ __global__ __launch_bounds__(64) void endpoint_rule_kernel(const double* __restr
     }
 }
 
-// Endpoint-trimmed copy of a ragged batch (model.py:52-64 without augmentation): utterance b keeps
-// samples [lo_b, hi_b) and is divided by its population standard deviation when `unit_variance`
-// (sklearn scale(with_mean=False), zero std -> 1).  One workgroup per utterance; fp64 statistics.
 // configs[3] glue, all on the device: endpoint frame indices -> what the trim and feature kernels need.
 //   seg[b]      = (int((left  * step) * rate), int((right * step) * rate)) clipped to the clip length
 //                 (endpoint.py:64: fp64 products in that order, truncation; numpy slicing clips at the end;
@@ -714,6 +751,9 @@ __global__ __launch_bounds__(1024) void endpoint_layout_kernel(const int32_t* __
     }
 }
 
+// Endpoint-trimmed copy of a ragged batch (model.py:52-64 without augmentation): utterance b keeps
+// samples [lo_b, hi_b) and is divided by its population standard deviation when `unit_variance`
+// (sklearn scale(with_mean=False), zero std -> 1).  One workgroup per utterance; fp64 statistics.
 template <int DTYPE>
 __global__ __launch_bounds__(256) void trim_scale_kernel(const void* __restrict__ wave, const int64_t* __restrict__ src_off,
                                                          const int64_t* __restrict__ seg, const int64_t* __restrict__ dst_off,
