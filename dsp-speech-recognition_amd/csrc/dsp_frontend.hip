@@ -49,7 +49,7 @@ int upload(T** d, const T* h, size_t n) {
 int grid_for(int64_t work_items, int per_block) {
     int64_t blocks = (work_items + per_block - 1) / per_block;
     if (blocks < 1) blocks = 1;
-    const int64_t cap = 256 * 8;  // 256 CUs x 8 resident blocks; the kernels grid-stride beyond
+    const int64_t cap = (int64_t)dsp_cu_count() * 8;  // CUs x 8 resident blocks; the kernels grid-stride beyond
     return (int)(blocks < cap ? blocks : cap);
 }
 

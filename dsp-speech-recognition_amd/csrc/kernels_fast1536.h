@@ -702,7 +702,7 @@ template <int NI, int NC, int NSTAGE, int DTYPE, bool RAGGED>
 static int fast1536_launch_k(const F1536Params& P, const void* d_wave, const BatchGeom& bg, float* d_out,
                              int64_t ld_out, int64_t groups_bound, hipStream_t st) {
     const size_t lds = ((size_t)P.tab_floats + (size_t)F1536_WAVES * P.wave_floats) * sizeof(float);
-    const int64_t cap = 256;  // one 8-wave workgroup per CU (LDS bound); the kernel deals the partial last round
+    const int64_t cap = dsp_cu_count();  // one 8-wave workgroup per CU (LDS bound); the kernel deals the partial last round
     int64_t blocks = (groups_bound + F1536_WAVES - 1) / F1536_WAVES;
     if (blocks > cap) blocks = cap;
     auto k = mfcc1536_kernel<NI, NC, NSTAGE, DTYPE, F1536_WAVES, RAGGED>;

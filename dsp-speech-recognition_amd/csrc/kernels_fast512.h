@@ -828,7 +828,7 @@ static int fast512_launch_k(const F512Params& P, const void* d_wave, const Batch
                             int64_t ld_out, int64_t groups_bound, hipStream_t st) {
     const size_t lds = ((size_t)P.tab_floats + (size_t)F512_WAVES * F512_WAVE_FLOATS) * sizeof(float);
     // balanced persistent grid: every wave runs the same number of groups (no ragged last round)
-    const int64_t cap = 256 * (16 / F512_WAVES);  // 256 CUs x resident workgroups (<= 16 waves per CU)
+    const int64_t cap = (int64_t)dsp_cu_count() * (16 / F512_WAVES);  // CUs x resident workgroups (<= 16 waves per CU)
     int64_t blocks = (groups_bound + F512_WAVES - 1) / F512_WAVES;
     static const int grid_mode = [] { const char* e = getenv("DSP_F512_GRID"); return e ? atoi(e) : 1; }();
     if (blocks > cap) {

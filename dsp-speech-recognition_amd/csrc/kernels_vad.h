@@ -439,7 +439,7 @@ static int vad_tile_launch_k(const VadParams& P, const BatchGeom& bg, const void
                              int32_t* d_zcr, int64_t groups_bound, hipStream_t st) {
     const size_t lds = (size_t)VAD_WAVES * P.wave_floats * sizeof(float);
     int64_t blocks = (groups_bound + VAD_WAVES - 1) / VAD_WAVES;
-    const int64_t cap = 256 * 3;   // <= 48 KB per workgroup: three resident workgroups per CU
+    const int64_t cap = (int64_t)dsp_cu_count() * 3;   // <= 48 KB per workgroup: three resident workgroups per CU
     if (blocks > cap) {
         const int64_t rounds = (blocks + cap - 1) / cap;
         blocks = (blocks + rounds - 1) / rounds;
@@ -461,7 +461,7 @@ static int vad_tile_launch_k(const VadParams& P, const BatchGeom& bg, const void
             int per_cu = (int)((size_t)(150 * 1024) / (lds3 ? lds3 : 1));
             if (per_cu > 8) per_cu = 8;
             if (per_cu < 1) per_cu = 1;
-            const int64_t cap3 = 256 * (int64_t)per_cu;
+            const int64_t cap3 = (int64_t)dsp_cu_count() * per_cu;
             if (blocks3 > cap3) blocks3 = cap3;
             if (f32_exact) {
                 auto k = vad_sum_kernel<DTYPE, FR, RAGGED, true>;
@@ -488,7 +488,7 @@ static int vad_tile_launch_k(const VadParams& P, const BatchGeom& bg, const void
         static size_t granted[DSP_MAX_DEVICES] = {};
         if (lds2 > 48 * 1024 && dsp_ensure_dynamic_lds((const void*)k, lds2, granted) != 0) return DSP_EHIP;
         int64_t blocks2 = (groups_bound + VAD_WAVES - 1) / VAD_WAVES;
-        const int64_t cap2 = 256 * 2;
+        const int64_t cap2 = (int64_t)dsp_cu_count() * 2;
         if (blocks2 > cap2) {
             const int64_t rounds = (blocks2 + cap2 - 1) / cap2;
             blocks2 = (blocks2 + rounds - 1) / rounds;

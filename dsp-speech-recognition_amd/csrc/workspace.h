@@ -89,3 +89,17 @@ inline int dsp_ensure_dynamic_lds(const void* kernel, size_t bytes, size_t (&gra
     return 0;
 }
 
+
+// Compute units of the current device (256 on MI355X), read once per device: the persistent kernels size
+// their grids as CUs x resident workgroups per CU.
+inline int dsp_cu_count() {
+    static int cached[DSP_MAX_DEVICES] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DSP_MAX_DEVICES) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}

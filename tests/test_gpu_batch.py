@@ -421,3 +421,40 @@ def test_two_threads_calling_the_drop_in_do_not_share_scratch():
     for t in ts:
         t.join()
     assert not errs, errs
+
+
+def test_pipeline_launch_does_not_wait_for_the_device():
+    """configs[3] is a pure sequence of asynchronous launches: with ~0.2 s of other work already queued on
+    the stream, queueing the whole pipeline behind it returns long before that work has finished (any host
+    synchronisation, blocking copy or allocation inside would wait for it)."""
+    import time
+    import torch
+    from features import _native as nat
+    from features.pipeline import VadMfccPipeline
+    from golden_cases import make_signal
+    clips = [make_signal(('vad', 400 + i, 16000 + 900 * i)) for i in range(64)]
+    so = np.concatenate([[0], np.cumsum([len(c) for c in clips])]).astype(np.int64)
+    d_flat = torch.from_numpy(np.concatenate(clips)).cuda()
+    pipe = VadMfccPipeline(rate=16000, unit_variance=True, winfunc=np.hamming,
+                           **{k: v for k, v in CFG.items() if k != 'samplerate'})
+    lay = pipe.prepare(so, delta_n=2)
+    out = torch.empty((lay.frames_bound, lay.D), device='cuda')
+    st = torch.cuda.current_stream()
+    for _ in range(3):                                    # warm: pooled workspaces, code objects
+        pipe.launch(d_flat.data_ptr(), nat.WAVE_I16, lay, out.data_ptr(), st)
+    torch.cuda.synchronize()
+    ref = out.clone()
+    out.zero_()
+    torch.cuda.synchronize()
+    done = torch.cuda.Event()
+    t0 = time.perf_counter()
+    torch.cuda._sleep(int(4e8))                           # ~0.2 s of device time ahead of the pipeline
+    pipe.launch(d_flat.data_ptr(), nat.WAVE_I16, lay, out.data_ptr(), st)
+    t_queue = time.perf_counter() - t0
+    done.record(st)
+    still_running = not done.query()
+    torch.cuda.synchronize()
+    t_total = time.perf_counter() - t0
+    assert still_running and t_queue < 0.25 * t_total, (t_queue, t_total)
+    fo = lay.d_frame_off.download((len(clips) + 1,), np.int64)
+    assert torch.equal(out[:int(fo[-1])], ref[:int(fo[-1])])
