@@ -46,6 +46,8 @@ struct F512Params {
     int32_t span_vec;      // ceil((7 S + L) / 4): 16-byte vectors staged per wave
     int32_t len[F512_MAX_NI];  // padded (multiple of 8) taps per filter group
     int64_t groups_per_utt, total_groups;   // uniform batches
+    int32_t flat;          // uniform batches: groups are cut from the FLAT frame sequence (a group may span two utterances)
+    int32_t seam_off;      // ... then frames of the second utterance sit this many floats further into the LDS image
     const int32_t* group_off;                // ragged: [B+1] prefix of ceil(T_b / 8)
     const int32_t* group_utt;                // ragged: utterance of every frame group
 };
@@ -193,6 +195,7 @@ __device__ __forceinline__ float f512_shift_in(float v, float left) {
 // Where a frame group lives (all wave-uniform).
 struct F512Group {
     int utt, t0, T, nsamp;
+    int nf1;               // frames of the group that belong to `utt` (8 unless the group spans a seam)
     int64_t s0, row0;
 };
 
@@ -206,12 +209,22 @@ __device__ __forceinline__ F512Group f512_locate(const F512Params& P, const Batc
         g.nsamp = (int)(bg.sample_off[g.utt + 1] - g.s0);
         g.row0 = bg.frame_off[g.utt];
         g.T = (int)(bg.frame_off[g.utt + 1] - g.row0);
+        g.nf1 = 8;
     } else {
-        const int gpu = (int)P.groups_per_utt;
-        g.utt = G / gpu;
-        g.t0 = (G - g.utt * gpu) * 8;
         g.nsamp = (int)bg.uniform_samples;
         g.T = (int)bg.uniform_frames;
+        if (P.flat) {
+            // groups of 8 cut from the flat frame sequence: no frame slot is wasted at the end of an utterance
+            const int F0 = 8 * G;
+            g.utt = F0 / g.T;
+            g.t0 = F0 - g.utt * g.T;
+            g.nf1 = g.T - g.t0 < 8 ? g.T - g.t0 : 8;
+        } else {
+            const int gpu = (int)P.groups_per_utt;
+            g.utt = G / gpu;
+            g.t0 = (G - g.utt * gpu) * 8;
+            g.nf1 = 8;
+        }
         g.s0 = (int64_t)g.utt * bg.uniform_samples;
         g.row0 = (int64_t)g.utt * bg.uniform_frames;
     }
@@ -279,7 +292,7 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         // per-vector bookkeeping at all: one base pointer, immediate offsets, no masks.  Ragged batches load
         // such a group from its first sample as it stands (4-byte aligned vector loads, nothing outside the
         // utterance is touched), so its LDS image needs no alignment shift either.
-        const bool fast_stage = (NSTAGE * 256 <= F512_WAVE_FLOATS) && base + NSTAGE * 256 <= nsamp;
+        const bool fast_stage = (NSTAGE * 256 <= F512_WAVE_FLOATS) && grp.nf1 == 8 && base + NSTAGE * 256 <= nsamp;
         const int d = (RAGGED && !fast_stage) ? (int)(g0 & 3) : 0;   // LDS image starts d samples earlier (aligned)
 
         // ---- stage 7 S + L (+ d) samples: coalesced aligned 16 B loads, all issued before first use;
@@ -305,6 +318,48 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
                     y.w = fmaf(-P.preemph, x[2], x[3]);
                     *reinterpret_cast<float4*>(wbuf + 4 * lane + 256 * r) = y;
                 }
+            }
+        } else if (!RAGGED) {
+            // Dense batch, end of an utterance: zero padding past its last sample and, for flat grouping, the
+            // first frames of the NEXT utterance as a second segment `seam_off` floats behind where they would
+            // sit otherwise (frame slot f >= nf1 reads from f S + seam_off), so the two utterances' samples
+            // never overlap in LDS.  Everything is a multiple of 4 here: vectors are all-valid or all-padding.
+            const int nf1 = grp.nf1;
+            const int X = nf1 * P.S + P.seam_off;               // LDS float offset of segment 2
+            const bool seg2 = nf1 < 8 && utt + 1 < bg.n_utt;
+            const int span_vec = P.span_vec + (P.flat ? (P.seam_off >> 2) : 0);
+            constexpr int NR = NSTAGE + 1;
+            F512Raw<DTYPE> raw[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int v = lane + 64 * r, p = 4 * v;
+                const bool in2 = nf1 < 8 && p >= X;
+                const int rel = in2 ? p - X : base + p;
+                const bool ok = v < span_vec && rel < nsamp && (!in2 || seg2);
+                raw[r] = f512_load_raw<DTYPE>(wave, ok ? grp.s0 + (in2 ? (int64_t)nsamp : 0) + rel : 0);
+            }
+            float left = base > 0 ? dsp_load_sample<DTYPE>(wave, g0 - 1) : 0.f;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int v = lane + 64 * r, p = 4 * v;
+                const bool in2 = nf1 < 8 && p >= X;
+                const int rel = in2 ? p - X : base + p;
+                const bool ok = v < span_vec && rel < nsamp && (!in2 || seg2);
+                float x[4];
+                f512_unpack<DTYPE>(raw[r], x);
+                const float prev = f512_shift_in(x[3], left);
+                left = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[3]), 63));
+                float4 y;
+                y.x = (in2 && rel == 0) ? x[0] : fmaf(-P.preemph, prev, x[0]);   // an utterance's first sample is not filtered
+                y.y = fmaf(-P.preemph, x[0], x[1]);
+                y.z = fmaf(-P.preemph, x[1], x[2]);
+                y.w = fmaf(-P.preemph, x[2], x[3]);
+                const uint32_t m = ok ? 0xffffffffu : 0u;
+                y.x = __uint_as_float(__float_as_uint(y.x) & m);
+                y.y = __uint_as_float(__float_as_uint(y.y) & m);
+                y.z = __uint_as_float(__float_as_uint(y.z) & m);
+                y.w = __uint_as_float(__float_as_uint(y.w) & m);
+                if (v < span_vec) *reinterpret_cast<float4*>(wbuf + p) = y;
             }
         } else {
             {
@@ -363,7 +418,7 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         // ---- pass 1: window, complex FFT32 over n1 of (column 2c) + i (column 2c+1) ----
         cpx z[32];
         {
-            const float* frp = wbuf + d + f * P.S + 2 * c;
+            const float* frp = wbuf + d + f * P.S + 2 * c + ((!RAGGED && f >= grp.nf1) ? P.seam_off : 0);
             const uint32_t fr = f512_lds_addr(frp);
             const uint32_t wn = f512_lds_addr(s_win + 2 * c);
             if (RAGGED && (d & 1)) {
@@ -598,7 +653,9 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
             if (k + 8 < NC && c == k) v1 = cep[k + 8];
         }
         const int t = t0 + f;
-        if (t < T) {
+        // flat grouping: rows of the next utterance follow directly, valid while inside the batch
+        const bool row_ok = (!RAGGED && P.flat) ? (grp.row0 + t < bg.total_frames) : (t < T);
+        if (row_ok) {
             float* o = out + (grp.row0 + t) * ld_out;
             if (c < P.C) o[c] = v0;
             if (c + 8 < P.C) o[c + 8] = v1;
@@ -859,6 +916,18 @@ static int fast512_launch_t(F512Params P, const void* d_wave, int dtype, const B
     if (bg.uniform_samples > 0) {
         P.groups_per_utt = (bg.uniform_frames + 7) / 8;
         P.total_groups = P.groups_per_utt * bg.n_utt;
+        // Flat grouping (groups of 8 cut from the flat frame sequence, a group may span the seam between two
+        // utterances) wastes no frame slots at the end of an utterance: 99 frames are 13 groups of 8 otherwise
+        // (5 % idle slots).  Needs vector-aligned hops and room for the seam's second segment in the wave buffer.
+        const int seam = (P.L - P.S + 3) / 4 * 4;
+        static const bool no_flat = getenv("DSP_F512_NOFLAT") != nullptr;   // A/B switch for tools/kbench.py
+        if (!no_flat && (P.S % 4) == 0 && P.L > P.S && bg.uniform_frames >= 8 && (bg.uniform_frames % 8) != 0 &&
+            7 * P.S + 16 * NROWS + seam + 4 <= F512_WAVE_FLOATS && 7 * P.S + 16 * NROWS + seam <= 256 * (NSTAGE + 1) &&
+            bg.total_frames + 8 <= 0x3fffffff) {
+            P.flat = 1;
+            P.seam_off = seam;
+            P.total_groups = (bg.total_frames + 7) / 8;
+        }
         if (dtype == DSP_WAVE_I16)
             return fast512_launch_k<NROWS, NI, NC, NSTAGE, DSP_WAVE_I16, false>(P, d_wave, bg, d_out, ld_out, P.total_groups, st);
         return fast512_launch_k<NROWS, NI, NC, NSTAGE, DSP_WAVE_F32, false>(P, d_wave, bg, d_out, ld_out, P.total_groups, st);
