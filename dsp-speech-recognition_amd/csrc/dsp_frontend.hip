@@ -473,6 +473,9 @@ int dsp_mfcc_delta_batch(const dsp_plan* plan, const void* d_wave, int wave_dtyp
                          void* stream) {
     if (!plan) return fail(DSP_EINVAL, "plan is NULL");
     if (delta_n < 1) return fail(DSP_EINVAL, "N must be an integer >= 1");  // base.py:71-72
+#ifdef DSP_WS_MALLOC_ASYNC
+    dsp_ws_diag_stream() = (hipStream_t)stream;
+#endif
     const int C = plan->C;
     if (C <= 0) return fail(DSP_EINVAL, "plan has no mel/DCT tables");
     int64_t uniform_frames = 0;

@@ -24,6 +24,15 @@ struct DspWorkspace {
     bool leased = false;
 };
 
+#ifdef DSP_WS_MALLOC_ASYNC
+// Diagnostic build only (tools/diag_malloc_async.py): the round-1 scheme this pool replaced -- every call
+// takes its tables from hipMallocAsync on the call's stream and hands them back with hipFreeAsync.
+inline hipStream_t& dsp_ws_diag_stream() {
+    thread_local hipStream_t st = nullptr;
+    return st;
+}
+#endif
+
 class DspWorkspacePool {
   public:
     // Returns nullptr on HIP failure.  The buffer stays leased until release().
@@ -31,6 +40,15 @@ class DspWorkspacePool {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) return nullptr;
         if (bytes < 256) bytes = 256;
+#ifdef DSP_WS_MALLOC_ASYNC
+        {
+            DspWorkspace* w = new DspWorkspace();
+            if (hipMallocAsync(&w->ptr, bytes, dsp_ws_diag_stream()) != hipSuccess) { delete w; return nullptr; }
+            w->bytes = bytes;
+            w->device = dev;
+            return w;
+        }
+#endif
         std::lock_guard<std::mutex> lk(mu_);
         for (DspWorkspace* w : all_) {
             if (w->leased || w->device != dev || w->bytes < bytes) continue;
@@ -60,6 +78,13 @@ class DspWorkspacePool {
 
     // Marks the buffer reusable once everything queued on `st` so far has finished.
     int release(DspWorkspace* w, hipStream_t st) {
+#ifdef DSP_WS_MALLOC_ASYNC
+        {
+            const hipError_t e = hipFreeAsync(w->ptr, st);
+            delete w;
+            return e == hipSuccess ? 0 : -1;
+        }
+#endif
         hipError_t e = hipEventRecord(w->done, st);
         std::lock_guard<std::mutex> lk(mu_);
         w->leased = false;

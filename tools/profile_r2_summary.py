@@ -79,7 +79,7 @@ try:
     print('traffic:', json.dumps(traffic))
     b = res['pmc_b']['mfcc512_kernel']
     a = res['pmc_a']['mfcc512_kernel']
-    groups = B * 13
+    groups = B * T // 8        # flat grouping: 8 frames per wave iteration, no idle frame slots
     instr = {
         '_comment': 'per-dispatch SQ counters of mfcc512_kernel at configs[1] (tools/kbench.py under rocprofv3 --pmc); '
                     'SQ_INSTS_* are wave instructions summed over the chip',
