@@ -458,3 +458,24 @@ def test_pipeline_launch_does_not_wait_for_the_device():
     assert still_running and t_queue < 0.25 * t_total, (t_queue, t_total)
     fo = lay.d_frame_off.download((len(clips) + 1,), np.int64)
     assert torch.equal(out[:int(fo[-1])], ref[:int(fo[-1])])
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.int16])
+def test_flat_grouping_across_utterance_seams(dtype):
+    """Dense batches cut their 8-frame groups from the flat frame sequence (kernels_fast512.h): a group may
+    hold the last frames of one utterance and the first of the next.  Every frame count around the group
+    size, batch sizes that end inside a group, against the oracle and against single-utterance calls."""
+    from features.batch import FeaturePlan
+    plan = FeaturePlan(winfunc=np.hamming, **CFG)
+    for T, B in ((7, 5), (8, 3), (9, 4), (15, 2), (17, 33), (23, 1), (99, 6)):
+        N = 400 + 160 * (T - 1) - 40          # T frames, the last one zero padded; multiple of 4
+        assert N % 4 == 0
+        waves = _batch(300 + T, B, N, dtype=dtype)
+        out, fo = plan.mfcc_batch(waves, delta_n=2)
+        assert fo[-1] == B * T and out.shape == (B * T, 39)
+        for b in range(B):
+            ref = dsp_oracle.mfcc_delta(waves[b].astype(np.float64), delta_n=2, winfunc=np.hamming, **CFG)
+            assert ref.shape[0] == T
+            assert normwise(out[fo[b]:fo[b + 1]], ref) <= TOL, (T, B, b)
+        single = np.concatenate([plan.mfcc_batch(waves[b:b + 1], delta_n=2)[0] for b in range(B)])
+        assert np.array_equal(out, single), (T, B)       # where a frame sits in its group changes nothing
