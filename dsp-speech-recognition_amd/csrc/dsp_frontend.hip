@@ -633,6 +633,15 @@ int dsp_model_finalize_batch(const float* d_mfcc, int64_t ld_in, const int64_t* 
     return DSP_OK;
 }
 
+int dsp_model_timefeat_batch(const double* d_amp_sum, const int64_t* d_frame_offsets, int32_t n_utt,
+                             int32_t frame_len, int32_t max_len, float* d_out, void* stream) {
+    if (!d_amp_sum || !d_frame_offsets || !d_out || n_utt <= 0 || frame_len <= 0 || max_len <= 0)
+        return fail(DSP_EINVAL, "dsp_model_timefeat_batch: bad arguments");
+    timefeat_finalize_kernel<<<n_utt, 64, 0, (hipStream_t)stream>>>(d_amp_sum, d_frame_offsets, n_utt, frame_len, max_len, d_out);
+    HIP_TRY(hipGetLastError());
+    return DSP_OK;
+}
+
 int dsp_pitch_scores_batch(const float* d_sig, const int64_t* d_sample_offsets, const int64_t* d_frame_offsets,
                            int32_t n_utt, int64_t n_frames_total, int64_t uniform_samples, int32_t frame_len,
                            int32_t frame_step, const float* d_taps, int32_t center_clip, int32_t lag_min,

@@ -420,10 +420,11 @@ __global__ __launch_bounds__(256) void vad_features_kernel(const void* __restric
                                                            int32_t S, int32_t use_sq, double* __restrict__ amp_sum,
                                                            int32_t* __restrict__ zcr) {
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t n_tiles = (bg.total_frames + 3) / 4;
+    const int64_t total_frames = bg.frame_off ? bg.frame_off[bg.n_utt] : bg.total_frames;   // ragged: the table is the truth
+    const int64_t n_tiles = (total_frames + 3) / 4;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t g = tile * 4 + wid;
-        if (g >= bg.total_frames) continue;
+        if (g >= total_frames) continue;
         int32_t utt;
         int64_t t, s0, nsamp;
         dsp_locate(bg, g, utt, t, s0, nsamp);
@@ -808,6 +809,46 @@ __global__ __launch_bounds__(256) void trim_scale_kernel(const void* __restrict_
     }
     for (; i < n; i += 256)
         dst[i] = (float)((double)dsp_load_sample<DTYPE>(wave, s0 + i) * inv);
+}
+
+// Optional amplitude stream of model.py:97-101 (cfg.use_timefeat) for a whole batch: per utterance
+//   a[t]  = amp_sum[t] / L                 get_amplitude of the trimmed, scaled clip (endpoint.py:109-131)
+//   z     = (a - mean) / std               sklearn scale: population std, 0 -> 1
+//   out[t, b, 0] = z[t], out[t, b, 1] = z[t + 1] - z[t]  (deviation, model.py:29-33: T - 1 rows),
+// each zero padded / truncated to max_len rows (model.py:35-50).  One wave per utterance, fp64.
+__global__ __launch_bounds__(64) void timefeat_finalize_kernel(const double* __restrict__ amp_sum,
+                                                               const int64_t* __restrict__ frame_off, int32_t n_utt,
+                                                               int32_t L, int32_t max_len, float* __restrict__ out) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int64_t base = frame_off[b];
+    const int T = (int)(frame_off[b + 1] - base);
+    const double* a = amp_sum + base;
+    const double inv_L = 1.0 / (double)L;
+    double s = 0.0;
+    for (int t = lane; t < T; t += 64) s += a[t] * inv_L;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const double mu = T > 0 ? s / (double)T : 0.0;
+    double v = 0.0;
+    for (int t = lane; t < T; t += 64) {
+        const double d = a[t] * inv_L - mu;
+        v += d * d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const double sd = T > 0 ? sqrt(v / (double)T) : 0.0;
+    const double inv = sd == 0.0 ? 1.0 : 1.0 / sd;
+    for (int t = lane; t < max_len; t += 64) {
+        float z0 = 0.f, z1 = 0.f;
+        if (t < T) {
+            const double zt = (a[t] * inv_L - mu) * inv;
+            z0 = (float)zt;
+            if (t + 1 < T) z1 = (float)((a[t + 1] * inv_L - mu) * inv - zt);
+        }
+        float* o = out + ((int64_t)t * n_utt + b) * 2;
+        o[0] = z0;
+        o[1] = z1;
+    }
 }
 
 // model.py:66-88 after the MFCC call, plus the 200-frame layout of model.py:35-50,131-135, one

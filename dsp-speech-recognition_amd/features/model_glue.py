@@ -153,19 +153,22 @@ class ModelFeatureBatch:
             j[b, 1] = rng.randint(0, hi)
         return j
 
-    def run(self, waves, sample_offsets=None, jitter=None, layout=None):
-        """-> (inp [max_len, B, 39] torch tensor on the library's device, len0 [B], endpoints [B, 2]).
+    def run(self, waves, sample_offsets=None, jitter=None, layout=None, use_pitch=False, use_timefeat=False):
+        """-> (inp [max_len, B, 39 (+2) (+2)] torch tensor on the library's device, len0 [B], endpoints [B, 2]).
         ``jitter``: int [B, 2] endpoint offsets (see draw_jitter) for the training path (augment=True);
-        None = test path.  torch only owns the result tensors, which go straight into the classifier."""
+        None = test path.  ``use_timefeat`` / ``use_pitch`` append the optional streams of model.py:125-128
+        in the reference's order (pitch, then amplitude): the amplitude stream is computed on the device
+        (dsp_vad_features_batch on the trimmed clips + dsp_model_timefeat_batch); the pitch stream runs the
+        per-utterance pitch tracker on the trimmed clips (its smoothing / octave repair is sequential host
+        logic), which costs a download and a host loop.  torch only owns the result tensors."""
         import torch
         from . import _native as nat
         from .batch import _is_device_tensor, _stream_ptr
         lib = nat.load()
         dev = waves.device if _is_device_tensor(waves) else torch.device('cuda', nat.current_device())
         stream = torch.cuda.current_stream(dev)
-        with torch.cuda.stream(stream):
-            (d_m0, lay), _, _ = self.pipe.run(waves, sample_offsets, delta_n=0, download=False, layout=layout,
-                                              jitter=jitter)
+        (d_m0, lay), _, _ = self.pipe.run(waves, sample_offsets, delta_n=0, download=False, layout=layout,
+                                          jitter=jitter)
         B, C = lay.n_utt, self.pipe.features.C
         inp = torch.empty((self.max_len, B, 3 * C), dtype=torch.float32, device=dev)
         len0 = torch.empty(B, dtype=torch.int32, device=dev)
@@ -173,6 +176,51 @@ class ModelFeatureBatch:
         st = _stream_ptr(stream) if _is_device_tensor(waves) else None
         nat.check(lib.dsp_model_finalize_batch(d_m0.ptr, C, lay.d_frame_off.ptr, B, C, self.delta_n, self.max_len,
                                                inp.data_ptr(), len0.data_ptr(), st))
-        seg = lay.d_seg.download((B, 2), np.int64, st)       # first host synchronisation of the call
+        extra = []
+        if use_pitch:
+            extra.append(self._pitch_streams(lay, st, dev))
+        if use_timefeat:
+            extra.append(self._timefeat_streams(lay, st, dev))
+        seg = lay.d_seg.download((B, 2), np.int64, st)       # first host synchronisation of the default call
         nat.check(lib.dsp_stream_synchronize(st))            # d_m0 is freed on return: its consumer has finished
+        if extra:
+            inp = torch.cat([inp] + extra, dim=2)
         return inp, len0.cpu().numpy(), seg
+
+    def _timefeat_streams(self, lay, st, dev):
+        """[max_len, B, 2]: z-scored frame amplitude of the trimmed, scaled clips and its first difference
+        (model.py:97-101), on the device."""
+        import torch
+        from . import _native as nat
+        lib = nat.load()
+        ep, fp = self.pipe.endpoint, self.pipe.features
+        L2, S2 = int(self.rate * ep.frame), int(ep.step * self.rate)       # to_frames truncation, sigproc.py:19
+        if (L2, S2) != (fp.L, fp.S):
+            raise NotImplementedError('amplitude framing differs from the MFCC framing at this rate; use '
+                                      'feature_extract_timespace per utterance')
+        B = lay.n_utt
+        d_amp = torch.empty(max(lay.frames_bound, 1), dtype=torch.float64, device=dev)
+        d_zcr = torch.empty(max(lay.frames_bound, 1), dtype=torch.int32, device=dev)
+        nat.check(lib.dsp_vad_features_batch(lay.d_trim.ptr, nat.WAVE_F32, lay.d_dst_off.ptr, lay.d_frame_off.ptr, B,
+                                             lay.frames_bound, 0, L2, S2, 0, d_amp.data_ptr(), d_zcr.data_ptr(), st))
+        out = torch.empty((self.max_len, B, 2), dtype=torch.float32, device=dev)
+        nat.check(lib.dsp_model_timefeat_batch(d_amp.data_ptr(), lay.d_frame_off.ptr, B, L2, self.max_len,
+                                               out.data_ptr(), st))
+        nat.check(lib.dsp_stream_synchronize(st))            # d_amp / d_zcr are released on return
+        return out
+
+    def _pitch_streams(self, lay, st, dev):
+        """[max_len, B, 2]: pitch track / 150 and its first difference (model.py:90-95) of the trimmed, scaled
+        clips.  The tracker's score kernel is batched per clip; smoothing, arg-max and octave repair are the
+        reference's sequential host logic, so this stream downloads the clips and loops over them."""
+        import torch
+        B = lay.n_utt
+        dst = lay.d_dst_off.download((B + 1,), np.int64, st)
+        clips = lay.d_trim.download((int(dst[-1]),), np.float32, st)
+        out = np.zeros((self.max_len, B, 2), dtype=np.float32)
+        for b in range(B):
+            p0, p1 = feature_extract_pitch(clips[dst[b]:dst[b + 1]].astype(np.float64), self.rate)
+            n0, n1 = min(len(p0), self.max_len), min(len(p1), self.max_len)
+            out[:n0, b, 0] = p0[:n0, 0]
+            out[:n1, b, 1] = p1[:n1, 0]
+        return torch.from_numpy(out).to(dev)

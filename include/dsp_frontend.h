@@ -218,6 +218,16 @@ int dsp_model_finalize_batch(const float* d_mfcc, int64_t ld_in, const int64_t* 
                              int32_t n_utt, int32_t C, int32_t N, int32_t max_len, float* d_out,
                              int32_t* d_len0, void* stream);
 
+/*
+ * Optional amplitude stream of model.py:97-101 (cfg.use_timefeat), batched: d_amp_sum = per-frame sums of
+ * |x| of the trimmed, scaled clips (dsp_vad_features_batch at frame_len = int(rate * cfg.frame)), one run of
+ * frames per utterance.  Writes d_out[max_len, n_utt, 2]: column 0 = the z-scored frame amplitude
+ * (endpoint.amplitude_feature, endpoint.py:128-131, through sklearn scale: population std, 0 -> 1), column 1 =
+ * its first difference (model.py:29-33, T - 1 rows), both zero padded / truncated to max_len (model.py:35-50).
+ */
+int dsp_model_timefeat_batch(const double* d_amp_sum, const int64_t* d_frame_offsets, int32_t n_utt,
+                             int32_t frame_len, int32_t max_len, float* d_out, void* stream);
+
 /* ---- pitch scores ------------------------------------------------------ */
 /*
  * Per frame of the (already 10 kHz) signal, rectangular frames of frame_len / hop frame_step as
