@@ -173,6 +173,12 @@ def other_paths(dev):
     return out
 
 
+# Rehearsal of the N > 1 path on a box with fewer GPUs (tests only): BENCH_REHEARSE_GLOO=1 lets every rank use
+# cuda:0 and runs the control-plane collectives over gloo on CPU tensors.  Never set by the driver; the line
+# then says "rehearsal": true and its value is meaningless.
+REHEARSE = os.environ.get('BENCH_REHEARSE_GLOO') == '1'
+
+
 def _free_port():
     import socket
     with socket.socket() as sk:
@@ -187,14 +193,14 @@ def launch_ranks(args):
     import subprocess
     import torch
     n_dev = torch.cuda.device_count()
-    if args.gpus > n_dev:
+    if args.gpus > n_dev and not (REHEARSE and n_dev >= 1):
         sys.stderr.write(f'bench.py: --gpus {args.gpus} requested but only {n_dev} GPU(s) are visible on this '
                          f'node; refusing to report an {args.gpus}-GPU number from fewer devices\n')
         raise SystemExit(2)
     port = _free_port()
     procs = []
     for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(0 if REHEARSE else r), WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
@@ -235,6 +241,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
+    if REHEARSE:
+        local_rank = 0
     if local_rank >= torch.cuda.device_count():
         raise SystemExit(f'bench.py: rank {rank} has no GPU (LOCAL_RANK {local_rank}, '
                          f'{torch.cuda.device_count()} visible)')
@@ -242,7 +250,11 @@ def main():
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if REHEARSE:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    cdev = torch.device('cpu') if REHEARSE else dev       # where the control-plane collectives live
 
     from features import _native as nat
     from features.batch import FeaturePlan
@@ -280,7 +292,7 @@ def main():
     def max_over_ranks(x):
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -363,7 +375,7 @@ def main():
 
     # --- configs[2]: RCCL all-gather of one step's features, timed on its own ---
     gather = None
-    if world > 1 and not args.no_gather:
+    if world > 1 and not args.no_gather and not REHEARSE:
         gbuf = torch.empty((world * B * T, D), dtype=torch.float32, device=dev)
         for _ in range(2):
             dist.all_gather_into_tensor(gbuf, outs[0][0])
@@ -378,10 +390,10 @@ def main():
                   'algbw_GBps': world * B * T * D * 4 / gms / 1e6}
     per_rank_ms = None
     if world > 1:
-        mine = torch.tensor([float(np.median([b[1] for b in blocks])) / args.steps], dtype=torch.float64, device=dev)
-        allr = torch.zeros(world, dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(allr, mine)
-        per_rank_ms = [float(x) for x in allr.cpu()]
+        mine = torch.tensor([float(np.median([b[1] for b in blocks])) / args.steps], dtype=torch.float64, device=cdev)
+        parts = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        per_rank_ms = [float(x.item()) for x in parts]
 
     # HBM traffic per launch measured with rocprofv3 PMC passes (cannot be collected inside this process)
     traffic, step_traffic, traffic_source = None, None, None
@@ -434,6 +446,8 @@ def main():
                      'compute': compute_roof(kernel_ms)},
         'parity_normwise_vs_oracle': parity,
     }
+    if REHEARSE:
+        res['rehearsal'] = True
     if per_rank_ms is not None:
         res['per_rank_ms_per_step'] = per_rank_ms
     if gather is not None:

@@ -111,3 +111,22 @@ def test_bench_rejects_launcher_mismatch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], capture_output=True,
                        text=True, timeout=300, env=env)
     assert r.returncode != 0 and 'WORLD_SIZE=4' in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal_on_one_gpu():
+    """The N > 1 control path of bench.py (rank launcher, barriers, max-over-ranks timing, per-rank gather of
+    the step times, one JSON line from rank 0) rehearsed with two ranks sharing cuda:0 over gloo -- the real
+    N > 1 run needs N GPUs and is the driver's."""
+    import json
+    env = dict(os.environ, BENCH_REHEARSE_GLOO='1')
+    env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '10', '--warmup', '2',
+                        '--min-time', '0.05', '--buffers', '2', '--no-cpu-baseline', '--no-extras'],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['rehearsal'] is True and len(j['per_rank_ms_per_step']) == 2
+    assert j['value'] > 0 and j['scaling'] == 'weak' and j['parity_normwise_vs_oracle'] <= 1e-4
