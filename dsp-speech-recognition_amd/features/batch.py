@@ -22,6 +22,15 @@ def _is_device_tensor(x):
     return hasattr(x, 'data_ptr') and getattr(x, 'is_cuda', False)
 
 
+def _check_device(x):
+    """A device tensor must live on the device the library is bound to (dsp_set_device): plans, scratch
+    and kernels follow the current HIP device, a tensor elsewhere would be written across devices."""
+    idx = getattr(getattr(x, 'device', None), 'index', None)
+    cur = nat.current_device()
+    if idx is not None and idx != cur:
+        raise nat.DspError(f'tensor lives on cuda:{idx}, the library is on device {cur} (dsp_set_device)')
+
+
 def _stream_ptr(stream):
     if stream is None:
         return None
@@ -130,6 +139,7 @@ class FeaturePlan:
         D = self.width(delta_n)
         if _is_device_tensor(waves):
             import torch
+            _check_device(waves)
             if not waves.is_contiguous():
                 waves = waves.contiguous()
             if out is None:
@@ -179,6 +189,7 @@ class EndpointPlan:
         d_ep = nat.SCRATCH.get('ep_batch', B * 8)
         if _is_device_tensor(waves):
             import torch
+            _check_device(waves)
             if not waves.is_contiguous():
                 waves = waves.contiguous()
             st = torch.cuda.current_stream(waves.device)
