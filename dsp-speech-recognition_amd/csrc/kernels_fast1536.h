@@ -215,9 +215,27 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mfcc1536_kernel(F1536Params P, 
     extern __shared__ __attribute__((aligned(256))) float smem_f[];
     float* const smem = smem_f;
     const int tid = threadIdx.x;
+    // dense batches: touch the first group's samples before the 33 KB of tables are copied, so the HBM latency
+    // of the wave's first loads overlaps the copy (kernels_fast512.h does the same)
+    float warm_ = 0.f;
+    if constexpr (!RAGGED) {
+        const int G0 = (int)blockIdx.x * WAVES + (tid >> 6);
+        if (G0 < (int)P.total_groups) {
+            const int64_t e = (int64_t)(G0 / (int)P.groups_per_utt) * bg.uniform_samples +
+                              (int64_t)(G0 % (int)P.groups_per_utt) * 4 * P.S;
+            const int64_t lim = (int64_t)bg.n_utt * bg.uniform_samples - 4;
+#pragma unroll
+            for (int r = 0; r < NSTAGE; ++r) {
+                int64_t idx = e + 4 * (tid & 63) + 256 * r;
+                idx = idx < lim ? idx : lim;
+                warm_ += dsp_load_sample<DTYPE>(wave, idx);
+            }
+        }
+    }
     for (int i = tid * 4; i < P.tab_floats; i += 64 * WAVES * 4)
         *reinterpret_cast<float4*>(smem + i) = *reinterpret_cast<const float4*>(P.tables + i);
     __syncthreads();
+    asm volatile("" :: "v"(warm_));   // the values are not used: this only keeps the warming loads alive
     const float* s_win = smem;
     const float2* s_w3 = reinterpret_cast<const float2*>(smem + P.off_w3);
     const float2* s_tw = reinterpret_cast<const float2*>(smem + P.off_tw);

@@ -245,9 +245,30 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
     const unsigned int stamp_entry_ = f512_clock();
     const unsigned int stamp_rt0_ = (unsigned int)__builtin_amdgcn_s_memrealtime();
 #endif
+    // Dense batches: touch the first group's samples before the tables are copied, so that the HBM latency of
+    // the wave's first loads overlaps the table copy (the data waits in L2 / the vector cache): at the start of
+    // a launch every wave is waiting for HBM at once and there is nothing else to run (45.9 -> 44.2 us).
+    float warm_ = 0.f;
+    if constexpr (!RAGGED) {
+        const int G0 = (int)blockIdx.x * WAVES + (tid >> 6);
+        if (G0 < (int)P.total_groups) {
+            const int64_t e = P.flat ? (int64_t)(8 * G0 / (int)bg.uniform_frames) * bg.uniform_samples +
+                                           (int64_t)(8 * G0 % (int)bg.uniform_frames) * P.S
+                                     : (int64_t)(G0 / (int)P.groups_per_utt) * bg.uniform_samples +
+                                           (int64_t)(G0 % (int)P.groups_per_utt) * 8 * P.S;
+            const int64_t lim = (int64_t)bg.n_utt * bg.uniform_samples - 4;
+#pragma unroll
+            for (int r = 0; r < NSTAGE; ++r) {
+                int64_t idx = e + 4 * (tid & 63) + 256 * r;
+                idx = idx < lim ? idx : lim;
+                warm_ += dsp_load_sample<DTYPE>(wave, idx);
+            }
+        }
+    }
     for (int i = tid * 4; i < P.tab_floats; i += 64 * WAVES * 4)
         *reinterpret_cast<float4*>(smem + i) = *reinterpret_cast<const float4*>(P.tables + i);
     __syncthreads();
+    asm volatile("" :: "v"(warm_));   // the values are not used: this only keeps the warming loads alive
     const float* s_win = smem;
     const float4* s_tw1 = reinterpret_cast<const float4*>(smem + P.off_tw1);
     const float* s_dct = smem + P.off_dct;
