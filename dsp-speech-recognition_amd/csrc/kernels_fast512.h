@@ -704,8 +704,7 @@ __global__ __launch_bounds__(1024) void f512_group_prefix_kernel(const int64_t* 
                                                                  int32_t tile_shift = 0,
                                                                  int64_t* __restrict__ tile_off = nullptr) {
     // optional second table in the same launch: tile_off[b] = sum_{i<b} ceil(T_i / 2^tile_shift) (the delta pass)
-    __shared__ int32_t part[1024];
-    __shared__ int32_t part_t[1024];
+    __shared__ int32_t wsum[16], wsum_t[16];
     const int tid = threadIdx.x;
     const int per = (n_utt + 1023) / 1024;
     const int lo = tid * per, hi = min(lo + per, n_utt);
@@ -716,18 +715,28 @@ __global__ __launch_bounds__(1024) void f512_group_prefix_kernel(const int64_t* 
         sum += (int32_t)((T + rnd) >> shift);
         sum_t += (int32_t)((T + rnd_t) >> tile_shift);
     }
-    part[tid] = sum;
-    part_t[tid] = sum_t;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan of the per-thread sums
-        const int32_t v = tid >= off ? part[tid - off] : 0, vt = tid >= off ? part_t[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        part_t[tid] += vt;
-        __syncthreads();
+    // inclusive scan of the per-thread sums: inside each wave with shuffles, across the 16 waves through LDS
+    int32_t inc = sum, inc_t = sum_t;
+    const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int32_t v = __shfl_up(inc, off, 64), vt = __shfl_up(inc_t, off, 64);
+        if (lane >= off) { inc += v; inc_t += vt; }
     }
-    int32_t run = part[tid] - sum;
-    int64_t run_t = part_t[tid] - sum_t;
+    if (lane == 63) { wsum[w] = inc; wsum_t[w] = inc_t; }
+    __syncthreads();
+    int32_t before = 0, before_t = 0, total = 0, total_t = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int32_t a = wsum[k], at = wsum_t[k];
+        if (k < w) { before += a; before_t += at; }
+        total += a;
+        total_t += at;
+    }
+    inc += before;
+    inc_t += before_t;
+    int32_t run = inc - sum;
+    int64_t run_t = inc_t - sum_t;
     for (int b = lo; b < hi; ++b) {
         group_off[b] = run;
         const int64_t T = frame_off[b + 1] - frame_off[b];
@@ -741,8 +750,8 @@ __global__ __launch_bounds__(1024) void f512_group_prefix_kernel(const int64_t* 
         }
     }
     if (tid == 1023) {
-        group_off[n_utt] = part[1023];
-        if (tile_off != nullptr) tile_off[n_utt] = part_t[1023];
+        group_off[n_utt] = total;
+        if (tile_off != nullptr) tile_off[n_utt] = total_t;
     }
 }
 
