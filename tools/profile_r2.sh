@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 rocprofv3 evidence (run on the GPU box from the repo root: gpurun -- 'bash tools/profile_r2.sh').
+# Round-2 rocprofv3 evidence (run on the GPU box from the repo root: gpurun -- "bash tools/profile_r2.sh").
 # Kernel-trace / stats passes and every --pmc pass are separate runs (never combined with other trace domains).
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/prof_r2
