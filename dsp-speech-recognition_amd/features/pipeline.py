@@ -34,6 +34,20 @@ class _Borrowed:
         self.ptr = int(ptr)
 
 
+class _TensorBuffer:
+    """Result rows held in a torch tensor (device-tensor inputs: torch's caching allocator instead of a
+    hipMalloc / hipFree pair per call); same surface as DeviceBuffer where the callers need it."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+        self.ptr = tensor.data_ptr()
+        self.nbytes = tensor.numel() * tensor.element_size()
+
+    def download(self, shape, dtype, stream=None):
+        n = int(np.prod(shape))
+        return self.tensor.reshape(-1)[:n].cpu().numpy().astype(dtype, copy=False).reshape(shape)
+
+
 class _DeviceLayout:
     """What FeaturePlan.run_raw needs, with the offsets living only on the device."""
 
@@ -136,7 +150,11 @@ class VadMfccPipeline:
         if jitter is not None:
             j = np.ascontiguousarray(jitter, dtype=np.int64).reshape(lay.n_utt, 2)
             d_jit = nat.device_array('pipe_jitter', j, _stream_ptr(stream)).ptr
-        d_out = nat.DeviceBuffer(max(lay.frames_bound, 1) * lay.D * 4)      # owned by the result
+        if _is_device_tensor(waves):
+            d_out = _TensorBuffer(torch.empty(max(lay.frames_bound, 1) * lay.D, dtype=torch.float32,
+                                              device=waves.device))
+        else:
+            d_out = nat.DeviceBuffer(max(lay.frames_bound, 1) * lay.D * 4)  # owned by the result
         self.launch(d_wave.ptr, dtype, lay, d_out.ptr, stream, d_jit)
         if not download:
             return (d_out, lay), None, None
