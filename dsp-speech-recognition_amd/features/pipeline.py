@@ -102,10 +102,30 @@ class VadMfccPipeline:
         self.unit_variance = bool(unit_variance)
         self.endpoint = EndpointPlan(rate, frame, step)
         self.features = FeaturePlan(**mfcc_kwargs)
+        import threading
+        self._tls = threading.local()   # per thread: last few batch shapes seen by run()
 
     def prepare(self, sample_offsets, delta_n=2):
         nat.require_device()
         return PipelineLayout(self, sample_offsets, delta_n)
+
+    def _cached_layout(self, sample_offsets, delta_n):
+        """run(download=True) without an explicit layout: batches of a shape this thread has seen recently reuse
+        their device tables and stage buffers (a training loop cycles through few batch shapes; building a
+        layout allocates and uploads, which costs more than the kernels).  Results that stay on the device
+        (download=False) never share a cached layout: their offsets live in the layout they are returned with."""
+        cache = getattr(self._tls, 'layouts', None)
+        if cache is None:
+            cache = self._tls.layouts = {}
+        so = np.ascontiguousarray(sample_offsets, dtype=np.int64)
+        key = (nat.current_device(), int(delta_n), so.tobytes())
+        lay = cache.pop(key, None)
+        if lay is None:
+            lay = PipelineLayout(self, so, delta_n)
+            while len(cache) >= 4:
+                cache.pop(next(iter(cache)))
+        cache[key] = lay               # most recently used last
+        return lay
 
     def launch(self, d_wave, wave_dtype, lay, d_out, stream=None, d_jitter=None):
         """Queue the whole pipeline on `stream` (raw pointers, no host synchronisation, no allocation):
@@ -131,7 +151,12 @@ class VadMfccPipeline:
         ((DeviceBuffer of [frames_bound, D] rows, PipelineLayout), None, None): the true frame offsets
         and endpoints are in layout.d_frame_off / layout.d_seg on the device."""
         nat.require_device()
-        lay = layout if layout is not None else self.prepare(sample_offsets, delta_n)
+        if layout is not None:
+            lay = layout
+        elif download:
+            lay = self._cached_layout(sample_offsets, delta_n)
+        else:
+            lay = self.prepare(sample_offsets, delta_n)
         stream = None
         if _is_device_tensor(waves):                # torch-ROCm tensor: nothing crosses PCIe
             import torch
