@@ -167,8 +167,9 @@ class ModelFeatureBatch:
         lib = nat.load()
         dev = waves.device if _is_device_tensor(waves) else torch.device('cuda', nat.current_device())
         stream = torch.cuda.current_stream(dev)
-        (d_m0, lay), _, _ = self.pipe.run(waves, sample_offsets, delta_n=0, download=False, layout=layout,
-                                          jitter=jitter)
+        if layout is None:       # this call consumes the layout's tables before it returns: a cached one is safe
+            layout = self.pipe._cached_layout(sample_offsets, 0)
+        (d_m0, lay), _, _ = self.pipe.run(waves, delta_n=0, download=False, layout=layout, jitter=jitter)
         B, C = lay.n_utt, self.pipe.features.C
         inp = torch.empty((self.max_len, B, 3 * C), dtype=torch.float32, device=dev)
         len0 = torch.empty(B, dtype=torch.int32, device=dev)
