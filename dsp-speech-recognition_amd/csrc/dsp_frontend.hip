@@ -444,14 +444,14 @@ int dsp_delta_batch(const float* d_in, int64_t ld_in, const int64_t* d_frame_off
                 d_in, ld_in, bg, D, N, inv_den, d_out, ld_out, d_out_dd, ld_out_dd, (int32_t)tiles, nullptr);
     } else if (uniform_frames <= 0 && lds <= 64 * 1024 && ld_in <= 0x7fffff && ld_out <= 0x7fffff && ld_out_dd <= 0x7fffff) {
         // ragged: per-utterance tile prefix in a pooled, event-guarded workspace, grid sized by a bound
-        static_assert(DT_TILE == 128, "shift below assumes 128-frame tiles");
+        static_assert(DT_TILE == (1 << DT_SHIFT), "tile tables are built with shifts");
         const int64_t bound = n_frames_total / DT_TILE + n_utt;
         if (bound > 0x7fffffff) return fail(DSP_EINVAL, "too many delta tiles");
         hipStream_t st = (hipStream_t)stream;
         DspWorkspace* w = dsp_workspace_pool().acquire(((size_t)n_utt + 1) * sizeof(int64_t));
         if (!w) return fail(DSP_EHIP, "workspace allocation failed");
         int64_t* tile_off = static_cast<int64_t*>(w->ptr);
-        prefix_ceil_kernel<<<1, 1024, 0, st>>>(d_frame_offsets, n_utt, 7, tile_off);
+        prefix_ceil_kernel<<<1, 1024, 0, st>>>(d_frame_offsets, n_utt, DT_SHIFT, tile_off);
         if (D == 13)
             delta_tiled_kernel<13><<<(int)bound, 256, lds, st>>>(d_in, ld_in, bg, D, N, inv_den, d_out, ld_out,
                                                                  d_out_dd, ld_out_dd, 0, tile_off);
@@ -529,7 +529,7 @@ int dsp_mfcc_delta_batch(const dsp_plan* plan, const void* d_wave, int wave_dtyp
                 int den = 0;
                 for (int i = 1; i <= delta_n; ++i) den += i * i;
                 const float inv_den = (float)(1.0 / (2.0 * den));
-                if (ragged && !have_pre) prefix_ceil_kernel<<<1, 1024, 0, st>>>(d_frame_offsets, n_utt, 7, tile_off);
+                if (ragged && !have_pre) prefix_ceil_kernel<<<1, 1024, 0, st>>>(d_frame_offsets, n_utt, DT_SHIFT, tile_off);
                 if (C == 13)
                     delta_rows_kernel<13><<<(int)blocks, 256, lds, st>>>(cep, bg, C, delta_n, inv_den, d_out, (int32_t)tiles, tile_off);
                 else

@@ -770,10 +770,10 @@ static inline void f512_build_group_tables(const int64_t* frame_off, int32_t n_u
                                            int32_t* group_off, int32_t* group_utt, hipStream_t st,
                                            int64_t* tile_off) {
     if (n_utt <= 4096) {
-        f512_group_prefix_kernel<<<1, 1024, 0, st>>>(frame_off, n_utt, shift, group_off, group_utt, 7, tile_off);
+        f512_group_prefix_kernel<<<1, 1024, 0, st>>>(frame_off, n_utt, shift, group_off, group_utt, DT_SHIFT, tile_off);
         return;
     }
-    f512_group_prefix_kernel<<<1, 1024, 0, st>>>(frame_off, n_utt, shift, group_off, nullptr, 7, tile_off);
+    f512_group_prefix_kernel<<<1, 1024, 0, st>>>(frame_off, n_utt, shift, group_off, nullptr, DT_SHIFT, tile_off);
     const int fill_blocks = (int)((n_utt + 255) / 256 < 1024 ? (n_utt + 255) / 256 : 1024);
     f512_group_fill_kernel<<<fill_blocks, 256, 0, st>>>(group_off, n_utt, group_utt);
 }

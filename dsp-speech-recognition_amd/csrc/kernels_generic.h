@@ -233,7 +233,10 @@ __global__ __launch_bounds__(256) void delta_kernel(const float* __restrict__ in
 // The tile's rows (plus a halo of 2N, edge-replicated at the utterance ends exactly like
 // numpy.pad(mode='edge') in base.py:75) go to LDS once; delta is formed in LDS for tile + halo N,
 // delta-delta from that, so every input value is read from HBM/L2 once instead of (2N+1)^2 times.
+#ifndef DT_TILE
 #define DT_TILE 128
+#define DT_SHIFT 7
+#endif
 // tile_off[b] = sum_{i<b} ceil(T_i / 2^shift), tile_off[n] = total (single block).
 __global__ __launch_bounds__(1024) void prefix_ceil_kernel(const int64_t* __restrict__ frame_off, int32_t n_utt,
                                                            int shift, int64_t* __restrict__ tile_off) {
