@@ -333,3 +333,35 @@ def test_model_feature_batch_optional_streams():
         m0 = min(len(p0), 200)
         same = np.isclose(got[:m0, b, 39], p0[:m0, 0], rtol=1e-5, atol=1e-6)
         assert same.mean() >= 0.98, (b, same.mean())       # fp32 clip vs fp64 clip: an arg-max may flip on a near tie
+
+
+def test_dense_feature_call_is_hip_graph_capturable():
+    """a dense dsp_features_batch launch allocates nothing and never synchronises, so it
+    can be captured into a HIP graph after one eager warm-up call and replayed on new data in the same buffers."""
+    import torch
+    from features import _native as nat
+    from features.batch import FeaturePlan
+    plan = FeaturePlan(samplerate=16000, winlen=0.025, winstep=0.01, numcep=13, nfilt=40, nfft=512, preemph=0.97,
+                       ceplifter=22, appendEnergy=True, winfunc=np.hamming)
+    B, N = 16, 16000
+    lay = plan.layout(np.empty((B, N), dtype=np.float32))
+    g = torch.Generator(device='cuda').manual_seed(3)
+    waves = 0.25 * torch.randn((B, N), device='cuda', generator=g)
+    out = torch.empty((lay.total_frames, 13), device='cuda')
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        plan.run_raw(waves.data_ptr(), nat.WAVE_F32, lay, out.data_ptr(), 0, side)      # eager warm-up
+    side.synchronize()
+    eager = out.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        plan.run_raw(waves.data_ptr(), nat.WAVE_F32, lay, out.data_ptr(), 0, torch.cuda.current_stream())
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    waves.mul_(0.5)                                # new data, same buffers
+    graph.replay()
+    torch.cuda.synchronize()
+    ref, _ = plan.mfcc_batch(waves)
+    assert torch.equal(out, ref)
