@@ -21,6 +21,8 @@ device-resident waveform.
 """
 from __future__ import annotations
 
+import threading
+
 import numpy as np
 
 from . import _native as nat
@@ -102,7 +104,6 @@ class VadMfccPipeline:
         self.unit_variance = bool(unit_variance)
         self.endpoint = EndpointPlan(rate, frame, step)
         self.features = FeaturePlan(**mfcc_kwargs)
-        import threading
         self._tls = threading.local()   # per thread: last few batch shapes seen by run()
 
     def prepare(self, sample_offsets, delta_n=2):
@@ -143,7 +144,8 @@ class VadMfccPipeline:
 
     def run(self, waves, sample_offsets=None, delta_n=2, download=True, layout=None, jitter=None):
         """waves: 1-D host array (int16 or float) or torch-ROCm tensor (int16 / float32) of concatenated
-        utterances; ``layout`` = a PipelineLayout from ``prepare`` (then sample_offsets is not needed).
+        utterances; ``layout`` = a PipelineLayout from ``prepare`` (then sample_offsets and delta_n are taken
+        from it).
         ``jitter``: optional int [B, 2] sample offsets added to (left, right) before trimming
         (model.py:54-60 draws them as -randint(0, 0.1 rate), +randint(0, 0.1 rate)).
         Returns (features [sum T_b, D] fp32, frame_offsets [B+1], endpoints [B, 2] in samples);
