@@ -91,12 +91,23 @@ __device__ __forceinline__ void f512_pin(T (&a)[N]) {
         else asm volatile("" : "+v"(a[i]));
     }
 }
+#ifdef F512_STAMP_ROUNDS   // per-ROUND timing instead of per phase: slot r = lifetime of the wave's r-th group, slot 4 + r = count
+#define F512_STAMP(i)                                                         \
+    do {                                                                      \
+        if ((i) == 0) stamp_prev_ = f512_clock();                             \
+        if ((i) == 10) {                                                      \
+            stamp_acc_[r < 4 ? r : 3] += f512_clock() - stamp_prev_;          \
+            stamp_acc_[4 + (r < 4 ? r : 3)] += 1;                             \
+        }                                                                     \
+    } while (0)
+#else
 #define F512_STAMP(i)                                     \
     do {                                                  \
         const unsigned int now_ = f512_clock();           \
         stamp_acc_[i] += now_ - stamp_prev_;              \
         stamp_prev_ = f512_clock();                       \
     } while (0)
+#endif
 #define F512_PIN(a) f512_pin(a)
 #else
 #define F512_STAMP(i) do {} while (0)

@@ -71,6 +71,12 @@ def main():
         for i in range(100):
             mfcc_only(i)
         raw.dsp_debug_read_stamps(buf, 16)
+        if os.environ.get('KBENCH_ROUNDS'):          # library built with -DF512_STAMPS -DF512_STAMP_ROUNDS
+            for r_ in range(4):
+                if buf[4 + r_]:
+                    print(f'  round {r_}: {buf[r_] / buf[4 + r_]:9.0f} cycles per group, {buf[4 + r_] / 100:8.0f} groups per launch')
+            print(f'  wave lifetime {buf[11] / max(buf[14], 1):9.0f} cycles, shader clock {buf[11] / max(buf[12], 1) * 0.1:5.2f} GHz')
+            return
         groups = 100 * B * ((T + 7) // 8)
         names = ['loop/locate', 'hbm load + stage', 'pass1 reads+window+FFT32', 'untangle+twiddle', 'exchange',
                  '2 x FFT16', 'power+packed unit+energy', 'ps write', 'mel+log', 'DCT+allreduce', 'store']
