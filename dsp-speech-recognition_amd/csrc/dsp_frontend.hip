@@ -19,7 +19,7 @@
 namespace {
 
 thread_local std::string g_err;
-std::atomic<int> g_force_generic{0};
+thread_local int g_force_generic = 0;   // test switch, per calling thread: other threads' calls are unaffected
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -150,7 +150,7 @@ extern "C" {
 int dsp_abi_version(void) { return DSP_ABI_VERSION; }
 
 int dsp_debug_force_generic(int on) {
-    g_force_generic.store(on ? 1 : 0);
+    g_force_generic = on ? 1 : 0;
     return DSP_OK;
 }
 
@@ -386,7 +386,7 @@ static int features_batch_impl(const dsp_plan* plan, const void* d_wave, int wav
     if (uniform_samples > 0 && bg.uniform_frames * n_utt != n_frames_total)
         return fail(DSP_EINVAL, "n_frames_total %lld != n_utt*T (%d*%lld)", (long long)n_frames_total, n_utt, (long long)bg.uniform_frames);
     hipStream_t st = (hipStream_t)stream;
-    if (out_kind == DSP_OUT_MFCC && !g_force_generic.load() && (plan->d_fast || plan->d_fast1536)) {
+    if (out_kind == DSP_OUT_MFCC && !g_force_generic && (plan->d_fast || plan->d_fast1536)) {
         BatchGeom fg = bg;
         const void* fw = d_wave;
         DspWorkspace* view = fused_kernel_view(fg, fw, wave_dtype, st);
@@ -565,7 +565,7 @@ int dsp_vad_features_batch(const void* d_wave, int wave_dtype, const int64_t* d_
     BatchGeom bg = make_geom(d_sample_offsets, d_frame_offsets, n_utt, n_frames_total, uniform_samples, frame_len, frame_step);
     hipStream_t st = (hipStream_t)stream;
     const int tile = vad_tile_frames(frame_len, frame_step);
-    if (!g_force_generic.load() && tile != 0) {
+    if (!g_force_generic && tile != 0) {
         BatchGeom fg = bg;
         const void* fw = d_wave;
         DspWorkspace* view = fused_kernel_view(fg, fw, wave_dtype, st);
@@ -659,7 +659,7 @@ int dsp_pitch_scores_batch(const float* d_sig, const int64_t* d_sample_offsets, 
     // register-blocked kernel (one wave per frame) where its shape constraints hold
     const int n_lags = lag_max - lag_min;
     const int W = frame_len <= 384 ? 3 : (frame_len <= 512 ? 4 : 0);
-    if (W != 0 && (lag_min % 4) == 0 && n_lags <= 256 && lag_max + 8 <= PITCH2_GUARD && !g_force_generic.load()) {
+    if (W != 0 && (lag_min % 4) == 0 && n_lags <= 256 && lag_max + 8 <= PITCH2_GUARD && !g_force_generic) {
         const int Lp = (frame_len + W - 1) / W * W;
         const size_t lds2 = (2 * (size_t)Lp + 2 * (size_t)Lp + (size_t)Lp + PITCH2_GUARD) * sizeof(float);
         const float2* tp = reinterpret_cast<const float2*>(d_taps);

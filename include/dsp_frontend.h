@@ -100,8 +100,9 @@ int dsp_plan_create(const dsp_plan_desc* desc, dsp_plan** plan);
 int dsp_plan_destroy(dsp_plan* plan);
 /* 1 if the plan is served by a specialised fused kernel (NFFT = 512 or 1536), 0 if only by the generic one */
 int dsp_plan_has_fast_path(const dsp_plan* plan);
-/* testing aid: route DSP_OUT_MFCC through the generic kernel even when the fast one applies
-   (process-wide flag; the two kernels are independent implementations and must agree) */
+/* testing aid: route the calling THREAD's feature / VAD / pitch calls through the generic kernels even when a
+   specialised one applies (thread-local flag: other threads are unaffected; the kernels are independent
+   implementations and must agree) */
 int dsp_debug_force_generic(int on);
 
 /* ---- the hot path -------------------------------------------------------------------------- */
