@@ -20,6 +20,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "dsp_common.h"
@@ -39,12 +40,12 @@
 struct F512Params {
     const float* tables;   // device blob copied to LDS by every workgroup
     int32_t tab_floats;    // multiple of 64 floats (256 B)
-    int32_t off_tw1, off_dct, off_melw, off_mels;
+    int32_t off_tw1, off_dct, off_melw, off_mels, off_bias;
     int32_t melw_row;      // floats per lane row of mel weights (multiple of 4, /4 odd: conflict-free b128)
     int32_t L, S, M, C, append_energy;
     float preemph;
     int32_t span_vec;      // ceil((7 S + L) / 4): 16-byte vectors staged per wave
-    int32_t len[F512_MAX_NI];  // padded (multiple of 8) taps per filter group
+    int32_t nb4[F512_MAX_NI];  // 16-byte blocks (4 taps) per filter iteration, the longest of its 8 slots
     int64_t groups_per_utt, total_groups;   // uniform batches
     int32_t flat;          // uniform batches: groups are cut from the FLAT frame sequence (a group may span two utterances)
     int32_t seam_off;      // ... then frames of the second utterance sit this many floats further into the LDS image
@@ -55,7 +56,8 @@ struct F512Params {
 struct Fast512Plan {
     float* d_tables;
     F512Params P;
-    int variant;           // which <NROWS, NI, NC> instantiation serves this plan
+    int variant;           // which <NROWS, NI> instantiation serves this plan
+    int caps;              // ... and which compile-time mel block table (0: counts from P.nb4)
 };
 
 template <int CTRL>
@@ -69,6 +71,32 @@ __device__ __forceinline__ float frame_allreduce(float v) {
     v += dpp_f32<0x141>(v);  // row_half_mirror: lane i <-> 7 - i inside each 8-lane half row
     return v;
 }
+
+// Compile-time mel block counts (16-byte blocks of 4 taps per filter iteration) of the two common plans, so
+// that the mel loop unrolls with immediate offsets.  A plan whose own counts fit under a table uses it (the
+// extra blocks carry zero weights); any other plan runs the CAPS = 0 instantiation with counts from P.nb4.
+//   CAPS 1: 40 filters, 16 kHz (the metric configuration; 33..40 filters at 8/16 kHz fit)   CAPS 2: 26 filters (base.py defaults)
+__host__ __device__ constexpr int f512_cap(int caps, int i) {
+    constexpr int c1[5] = {2, 3, 4, 5, 8}, c2[4] = {3, 4, 6, 12};
+    return caps == 1 ? c1[i] : c2[i];
+}
+__host__ __device__ constexpr int f512_cap_prefix(int caps, int i) {
+    int s = 0;
+    for (int k = 0; k < i; ++k) s += f512_cap(caps, k);
+    return s;
+}
+template <int I, int N, typename F>
+__device__ __forceinline__ void f512_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        f512_static_for<I + 1, N>(f);
+    }
+}
+// Which cepstral coefficient register r of lane c accumulates: r ^ f512_cbase(c).  The map is chosen so that the
+// three reduce-scatter steps (partners c^7, c^2, c^1: row_half_mirror and two quad_perms) need no selects:
+// cbase(c ^ 7) = cbase(c) ^ 8, cbase(c ^ 2) = cbase(c) ^ 4, cbase(c ^ 1) = cbase(c) ^ 2.
+__host__ __device__ constexpr int f512_cbase(int c) { return ((c & 1) ? 2 : 0) ^ ((c & 2) ? 4 : 0) ^ ((c & 4) ? 14 : 0); }
+typedef float f512_f2u __attribute__((ext_vector_type(2), aligned(4)));
 
 #define F512_FENCE() asm volatile("" ::: "memory")
 
@@ -245,7 +273,7 @@ __device__ __forceinline__ F512Group f512_locate(const F512Params& P, const Batc
 // RAGGED = false: dense [B, N] batch, N % 4 == 0 (every 16-byte vector is all-valid or all-padding).
 // RAGGED = true : concatenated utterances of any length at any offset; loads stay 16-byte aligned
 //                 (the LDS image starts at the aligned sample below the group's first one).
-template <int NROWS, int NI, int NC, int NSTAGE, int DTYPE, int WAVES, bool RAGGED>
+template <int NROWS, int NI, int CAPS, int NSTAGE, int DTYPE, int WAVES, bool RAGGED>
 __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_kernel(F512Params P, BatchGeom bg,
                                                              const void* __restrict__ wave,
                                                              float* __restrict__ out, int64_t ld_out) {
@@ -549,16 +577,19 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         // Lane 0 (c = 0) owns bins 16 j instead: the even ones (32 k) fit the same slots, bin 256 is
         // slot 8, slots 9..15 repeat bins 224..32, and the 8 odd ones (16, 48, .., 240) go to podd[].
         float podd[8];
-        float esum0 = 0.f;  // lane 0: sum over its 17 distinct bins
+        // energy: every lane sums its 32 bins; lane 0's first unit is replaced by its 17 distinct bins below
+        float e0 = p0[0], e1 = p1[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) { e0 += p0[k]; e1 += p1[k]; }
 #pragma unroll
         for (int m = 0; m < 8; ++m) podd[m] = 0.f;
         if (c == 0) {
             // u0 = FFT16 of r[2m] + i r[2m+1]; finish the 32-point real FFT R[j] = X[16 j], j = 0..16
             // (factor 8 carried: 1/16 relative to the other units)
             float R[17];
-            const float e0 = u0[0].x + u0[0].y, e16 = u0[0].x - u0[0].y;
-            R[0] = S2 * 4.f * e0 * e0;
-            R[16] = S2 * 4.f * e16 * e16;
+            const float f0 = u0[0].x + u0[0].y, f16 = u0[0].x - u0[0].y;
+            R[0] = S2 * 4.f * f0 * f0;
+            R[16] = S2 * 4.f * f16 * f16;
             R[8] = S2 * 4.f * fmaf(u0[8].x, u0[8].x, u0[8].y * u0[8].y);
 #pragma unroll
             for (int j = 1; j < 8; ++j) {
@@ -572,8 +603,10 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
                 R[j] = S2 * fmaf(rp.x, rp.x, rp.y * rp.y);
                 R[16 - j] = S2 * fmaf(rm.x, rm.x, rm.y * rm.y);
             }
+            float es = R[0];
 #pragma unroll
-            for (int j = 0; j < 17; ++j) esum0 += R[j];
+            for (int j = 1; j < 17; ++j) es += R[j];
+            e0 = es;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 p0[k] = R[2 * k];
@@ -581,16 +614,9 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
                 podd[k] = R[2 * k + 1];
             }
         }
-        float energy = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) energy += p0[k] + p1[k];
-        if (c == 0) {
-            energy = esum0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) energy += p1[k];
-        }
-        energy = S1 * frame_allreduce(energy);
-        if (energy == 0.f) energy = DSP_EPS_F32;
+        // |X|^2 / 512 with the factor 2 of the rows = 1 / 2048; the mel weights and this sum both carry an extra
+        // 2^32 (removed again after the logarithm), so that v_log_f32 never sees a denormal
+        float energy = (S1 * 4294967296.0f) * frame_allreduce(e0 + e1);
 
         F512_PIN(p0); F512_PIN(p1); F512_PIN(podd);
         F512_STAMP(6);
@@ -619,78 +645,106 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         F512_FENCE();
         F512_STAMP(7);
 
-        // ---- sparse mel triangles, log.  Lane c owns filters c + 8 i; its weights sit in one LDS
-        //      row, the spectrum bins of a filter are contiguous from a 16-byte aligned start, so both
-        //      are read as b128.  Blocks of 8 taps: all reads are issued before the first FMA. ----
+        // ---- sparse mel triangles, log2.  Lane c owns one filter slot per iteration i; its weights sit in one LDS
+        //      row, the spectrum bins of a filter are contiguous from a 16-byte aligned start, so both are read as
+        //      b128 blocks of 4 taps.  Weights carry 2^21 = 2^32 / 2048; an all-zero filter gives log2(eps 2^32) = -20
+        //      (base.py:30, eps = 2^-52). ----
         float lm[NI];
         {
             const float4* wrow = reinterpret_cast<const float4*>(s_melw + c * P.melw_row);
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
+            f512_static_for<0, NI>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
                 const float4* pb = reinterpret_cast<const float4*>(ps + __float_as_int(smem[P.off_mels + i * 8 + c]));
                 float acc0 = 0.f, acc1 = 0.f;
-                const int nb = P.len[i] >> 3;
-                for (int b = 0; b < nb; ++b) {
-                    const float4 w0 = wrow[2 * b], w1 = wrow[2 * b + 1];
-                    const float4 q0 = pb[2 * b], q1 = pb[2 * b + 1];
-                    __builtin_amdgcn_sched_barrier(0);
-                    acc0 = fmaf(w0.x, q0.x, acc0);
-                    acc1 = fmaf(w0.y, q0.y, acc1);
-                    acc0 = fmaf(w0.z, q0.z, acc0);
-                    acc1 = fmaf(w0.w, q0.w, acc1);
-                    acc0 = fmaf(w1.x, q1.x, acc0);
-                    acc1 = fmaf(w1.y, q1.y, acc1);
-                    acc0 = fmaf(w1.z, q1.z, acc0);
-                    acc1 = fmaf(w1.w, q1.w, acc1);
+                if constexpr (CAPS != 0) {
+                    constexpr int nb = f512_cap(CAPS, i), w0 = f512_cap_prefix(CAPS, i);
+#pragma unroll
+                    for (int b = 0; b < nb; ++b) {
+                        const float4 w = wrow[w0 + b], q = pb[b];
+                        acc0 = fmaf(w.x, q.x, acc0);
+                        acc1 = fmaf(w.y, q.y, acc1);
+                        acc0 = fmaf(w.z, q.z, acc0);
+                        acc1 = fmaf(w.w, q.w, acc1);
+                    }
+                } else {
+                    const int nb = P.nb4[i];
+#pragma unroll 2
+                    for (int b = 0; b < nb; ++b) {
+                        const float4 w = wrow[b], q = pb[b];
+                        acc0 = fmaf(w.x, q.x, acc0);
+                        acc1 = fmaf(w.y, q.y, acc1);
+                        acc0 = fmaf(w.z, q.z, acc0);
+                        acc1 = fmaf(w.w, q.w, acc1);
+                    }
+                    wrow += nb;
                 }
-                wrow += 2 * nb;
-                float acc = acc0 + acc1;
-                if (acc == 0.f) acc = DSP_EPS_F32;
-                lm[i] = __logf(acc);
-            }
+                const float acc = acc0 + acc1;
+                const float l2 = __builtin_amdgcn_logf(acc);
+                lm[i] = acc == 0.f ? -20.f : l2;
+            });
         }
         F512_FENCE();
         F512_PIN(lm);
         F512_STAMP(8);
         F512_PIN(lm);
 
-        // ---- DCT-II * lifter partial sums over this lane's filters, all-reduce over the frame ----
-        float cep[NC];
+        // ---- DCT-II * lifter.  The filter of slot (c, u) and the one of slot (7 - c, NI - 1 - u) are mirror images
+        //      (j and M - 1 - j), and DCT-II rows are (anti)symmetric under that mirror: even coefficients see the sum
+        //      of the two log energies, odd ones the difference -- half the multiply-adds.  Register r of lane c holds
+        //      coefficient r ^ cbase(c) (even r <-> even coefficient), see f512_cbase. ----
+        float cep[16];
 #pragma unroll
-        for (int k = 0; k < NC; ++k) cep[k] = 0.f;
+        for (int k = 0; k < 16; ++k) cep[k] = 0.f;
+        constexpr int NU = (NI + 1) / 2;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const float4* dr = reinterpret_cast<const float4*>(s_dct + (i * 8 + c) * 20);
+        for (int u = 0; u < NU; ++u) {
+            const float a = lm[u], b = dpp_f32<0x141>(lm[NI - 1 - u]);
+            const float sm = a + b, df = a - b;
+            const float4* dr = reinterpret_cast<const float4*>(s_dct + (u * 8 + c) * 20);
 #pragma unroll
-            for (int q = 0; q < (NC + 3) / 4; ++q) {
-                const float4 d = dr[q];
-                if (4 * q + 0 < NC) cep[4 * q + 0] = fmaf(d.x, lm[i], cep[4 * q + 0]);
-                if (4 * q + 1 < NC) cep[4 * q + 1] = fmaf(d.y, lm[i], cep[4 * q + 1]);
-                if (4 * q + 2 < NC) cep[4 * q + 2] = fmaf(d.z, lm[i], cep[4 * q + 2]);
-                if (4 * q + 3 < NC) cep[4 * q + 3] = fmaf(d.w, lm[i], cep[4 * q + 3]);
+            for (int q = 0; q < 4; ++q) {
+                const float4 t = dr[q];
+                cep[4 * q + 0] = fmaf(t.x, sm, cep[4 * q + 0]);
+                cep[4 * q + 1] = fmaf(t.y, df, cep[4 * q + 1]);
+                cep[4 * q + 2] = fmaf(t.z, sm, cep[4 * q + 2]);
+                cep[4 * q + 3] = fmaf(t.w, df, cep[4 * q + 3]);
             }
         }
+        // reduce-scatter over the frame's 8 lanes: 8 + 4 + 2 DPP adds, lane c ends with coefficients cbase(c), cbase(c) + 1
+        float h8[8], h4[4];
 #pragma unroll
-        for (int k = 0; k < NC; ++k) cep[k] = frame_allreduce(cep[k]);
-        if (P.append_energy) cep[0] = __logf(energy);
-
-        F512_PIN(cep);
-        F512_STAMP(9);
-        F512_PIN(cep);
-        // ---- store: lane c writes coefficients c and c + 8 of its frame ----
-        float v0 = cep[0], v1 = NC > 8 ? cep[8] : 0.f;
+        for (int r = 0; r < 8; ++r) h8[r] = cep[r] + dpp_f32<0x141>(cep[8 + r]);   // partner c ^ 7
 #pragma unroll
-        for (int k = 1; k < 8; ++k) {
-            if (k < NC && c == k) v0 = cep[k];
-            if (k + 8 < NC && c == k) v1 = cep[k + 8];
+        for (int r = 0; r < 4; ++r) h4[r] = h8[r] + dpp_f32<0x4E>(h8[4 + r]);      // partner c ^ 2
+        float v0 = h4[0] + dpp_f32<0xB1>(h4[2]);                                   // partner c ^ 1
+        float v1 = h4[1] + dpp_f32<0xB1>(h4[3]);
+        {
+            const float2 bias = *reinterpret_cast<const float2*>(smem + P.off_bias + 2 * c);   // removes the 2^32
+            v0 += bias.x;
+            v1 += bias.y;
         }
+        if (P.append_energy) {
+            constexpr float LN2 = 0.69314718055994530942f, LN_EPS = -36.04365338911715f;   // ln(2^-52), base.py:26
+            const float le = fmaf(__builtin_amdgcn_logf(energy), LN2, -32.f * LN2);
+            if (c == 0) v0 = energy == 0.f ? LN_EPS : le;
+        }
+
+        F512_STAMP(9);
+        // ---- store: lane c writes its two adjacent coefficients ----
+        const int cb = ((c & 1) << 1) ^ ((c & 2) << 1) ^ ((c & 4) ? 14 : 0);
         const int t = t0 + f;
         // flat grouping: rows of the next utterance follow directly, valid while inside the batch
         const bool row_ok = (!RAGGED && P.flat) ? (grp.row0 + t < bg.total_frames) : (t < T);
         if (row_ok) {
-            float* o = out + (grp.row0 + t) * ld_out;
-            if (c < P.C) o[c] = v0;
-            if (c + 8 < P.C) o[c + 8] = v1;
+            float* o = out + (grp.row0 + t) * ld_out + cb;
+            if (cb + 1 < P.C) {
+                f512_f2u v;
+                v.x = v0;
+                v.y = v1;
+                *reinterpret_cast<f512_f2u*>(o) = v;
+            } else if (cb < P.C) {
+                o[0] = v0;
+            }
         }
         F512_FENCE();
         F512_STAMP(10);
@@ -798,18 +852,32 @@ static inline bool fast512_shape_ok(const dsp_plan_desc* d) {
            d->nfilt <= 8 * F512_MAX_NI && d->numcep >= 1 && d->numcep <= 16;
 }
 
+// The DCT half of the kernel relies on D[k][M - 1 - j] = (-1)^k D[k][j] (true of every DCT-II * lifter matrix);
+// a caller-supplied matrix without that symmetry runs on the generic kernel.
+static inline bool fast512_dct_is_mirror_symmetric(const dsp_plan_desc* d) {
+    const int M = d->nfilt, C = d->numcep;
+    for (int k = 0; k < C; ++k) {
+        double mx = 0.0;
+        for (int j = 0; j < M; ++j) mx = std::max(mx, (double)std::fabs(d->h_dct[(size_t)k * M + j]));
+        const double sgn = (k & 1) ? -1.0 : 1.0;
+        for (int j = 0; j < M; ++j)
+            if (std::fabs((double)d->h_dct[(size_t)k * M + (M - 1 - j)] - sgn * (double)d->h_dct[(size_t)k * M + j]) > 2e-6 * mx) return false;
+    }
+    return true;
+}
+
 static inline int fast512_plan_init(dsp_plan* p, const dsp_plan_desc* d, const int32_t* mel_off) {
     p->d_fast = nullptr;
-    if (!fast512_shape_ok(d)) return DSP_OK;
+    if (!fast512_shape_ok(d) || !d->h_dct || !fast512_dct_is_mirror_symmetric(d)) return DSP_OK;
     const int M = d->nfilt, C = d->numcep, L = d->frame_len;
     const int ni_real = (M + 7) / 8, nrows = (L + 15) / 16;
-    int variant, NI;  // template instantiation: <NROWS, NI, NC>
+    int variant, NI;  // template instantiation: <NROWS, NI, CAPS>
     // The wave stages every sample its pass-1 rows will touch (16 x NROWS per frame, window zero beyond
     // L), so no multiply ever sees stale LDS.  +1 vector: ragged batches stage from an aligned start.
     const int span25 = 7 * d->frame_step + 400, span32 = 7 * d->frame_step + 512;
     const int nstage = ((span25 + 3) / 4 + 1 + 63) / 64;
-    if (nrows <= 25 && ni_real <= 4 && C <= 13 && nstage <= 6) { variant = 0; NI = 4; }
-    else if (nrows <= 25 && ni_real <= 5 && C <= 13 && nstage <= 6) { variant = 1; NI = 5; }
+    if (nrows <= 25 && ni_real <= 4 && nstage <= 6) { variant = 0; NI = 4; }
+    else if (nrows <= 25 && ni_real <= 5 && nstage <= 6) { variant = 1; NI = 5; }
     else { variant = 2; NI = F512_MAX_NI; }
     if (const char* fv = getenv("DSP_F512_FORCE_CATCHALL")) {  // debugging aid: run any plan on the catch-all instantiation
         if (fv[0] == '1') { variant = 2; NI = F512_MAX_NI; }
@@ -824,40 +892,79 @@ static inline int fast512_plan_init(dsp_plan* p, const dsp_plan_desc* d, const i
                 tw1[((k1 - 1) * 8 + c) * 4 + 2 * h] = (float)cos(a);
                 tw1[((k1 - 1) * 8 + c) * 4 + 2 * h + 1] = (float)sin(a);
             }
-    std::vector<float> dct((size_t)NI * 8 * 20, 0.f);  // 20-float rows: 5 x 16 B, conflict-free b128
-    for (int i = 0; i < NI; ++i)
+    // Filter slots: lane c, iteration i.  Filters are dealt in mirror pairs (j, M - 1 - j): pair p sits in slot
+    // (p % 8, p / 8) and its mirror image in slot (7 - p % 8, NI - 1 - p / 8); with an odd NI the middle iteration holds
+    // 4 pairs (lanes c and 7 - c).  The middle filter of an odd M fills both slots of its pair (half weight each).
+    // Iteration i so holds 8 filters of similar length: 8 i .. 8 i + 7 from below or their mirror images from above.
+    std::vector<int> slot((size_t)8 * NI, -1);
+    const int n_pairs = (M + 1) / 2, full = NI / 2;
+    if (n_pairs > 4 * NI) return DSP_OK;
+    for (int pr = 0; pr < n_pairs; ++pr) {
+        const int ja = pr, jb = M - 1 - pr;
+        int c, u;
+        if (pr < 8 * full) { c = pr % 8; u = pr / 8; }
+        else { c = pr - 8 * full; u = full; }
+        slot[(size_t)u * 8 + c] = ja;
+        slot[(size_t)(NI - 1 - u) * 8 + (7 - c)] = jb;
+    }
+    const int NU = (NI + 1) / 2;
+    const double LN2 = 0.69314718055994530942;
+    std::vector<float> dct((size_t)NU * 8 * 20, 0.f);  // [unit][lane] rows of 16 (+4 pad: 5 x 16 B, conflict-free b128)
+    std::vector<double> bias_acc(16, 0.0);
+    for (int u = 0; u < NU; ++u)
         for (int c = 0; c < 8; ++c) {
-            const int j = c + 8 * i;
-            if (j >= M) continue;
-            for (int k = 0; k < C; ++k) dct[((size_t)i * 8 + c) * 20 + k] = d->h_dct[(size_t)k * M + j];
+            const int ja = slot[(size_t)u * 8 + c], jb = slot[(size_t)(NI - 1 - u) * 8 + (7 - c)];
+            if (ja < 0) continue;
+            // the pair is visited from both of its lanes when it lies in the middle iteration of an odd NI, and a
+            // filter that is its own mirror image enters as a + b = 2 a
+            const bool both = (NI & 1) && u == NI / 2;
+            const double wgt = (both ? 0.5 : 1.0) * (ja == jb ? 0.5 : 1.0);
+            for (int r = 0; r < 16; ++r) {
+                const int k = r ^ f512_cbase(c);
+                if (k >= C) continue;
+                const float t = (float)(wgt * LN2 * (double)d->h_dct[(size_t)k * M + ja]);
+                dct[((size_t)u * 8 + c) * 20 + r] = t;
+                // every log2 carries +32 (weights scaled by 2^32): sums see +64, differences nothing
+                if ((r & 1) == 0) bias_acc[k] -= 64.0 * (double)t;
+            }
         }
+    std::vector<float> bias(16, 0.f);
+    for (int c = 0; c < 8; ++c)
+        for (int r = 0; r < 2; ++r) bias[2 * c + r] = (float)bias_acc[f512_cbase(c) + r];
     Fast512Plan* fp = new Fast512Plan();
     memset(fp, 0, sizeof(*fp));
-    // mel: per lane one row of weights (groups back to back); every filter starts on a bin that is
-    // a multiple of 4 (leading zero weights absorb the misalignment) and every group is padded to a
-    // multiple of 8 taps.  Padding weights are 0; padded reads stay inside the 264-float frame row.
-    int row_floats = 0;
+    // mel: per lane one row of weights (iterations back to back); every filter starts on a bin that is a multiple
+    // of 4 (leading zero weights absorb the misalignment) and every iteration is padded to whole 16-byte blocks.
+    // Padding weights are 0; padded reads stay inside the 264-float frame row.
+    int caps = variant == 0 ? 2 : (variant == 1 ? 1 : 0);
+    int row_blocks = 0;
     for (int i = 0; i < NI; ++i) {
         int len = 0;
         for (int c = 0; c < 8; ++c) {
-            const int j = c + 8 * i;
-            if (j >= M) continue;
+            const int j = slot[(size_t)i * 8 + c];
+            if (j < 0) continue;
             const int need = (d->h_mel_start[j] & 3) + d->h_mel_count[j];
             if (need > len) len = need;
         }
-        len = (len + 7) / 8 * 8;
-        fp->P.len[i] = len;
-        row_floats += len;
+        fp->P.nb4[i] = (len + 3) / 4;
+        if (caps != 0 && fp->P.nb4[i] > f512_cap(caps, i)) caps = 0;
     }
-    int melw_row = row_floats > 0 ? row_floats : 8;
+    if (const char* fc = getenv("DSP_F512_NOCAPS")) {  // A/B aid: run-time block counts for every plan
+        if (fc[0] == '1') caps = 0;
+    }
+    for (int i = 0; i < NI; ++i) {
+        if (caps != 0) fp->P.nb4[i] = f512_cap(caps, i);
+        row_blocks += fp->P.nb4[i];
+    }
+    int melw_row = row_blocks > 0 ? 4 * row_blocks : 4;
     if (((melw_row / 4) & 1) == 0) melw_row += 4;  // odd number of 16-byte slots per row
     std::vector<float> melw((size_t)8 * melw_row, 0.f), mels((size_t)NI * 8, 0.f);
     for (int c = 0; c < 8; ++c) {
         int pos = 0;
         for (int i = 0; i < NI; ++i) {
-            const int j = c + 8 * i, len = fp->P.len[i];
+            const int j = slot[(size_t)i * 8 + c], len = 4 * fp->P.nb4[i];
             int32_t start = 0;
-            if (j < M) {
+            if (j >= 0) {
                 start = d->h_mel_start[j] & ~3;
                 int lead = d->h_mel_start[j] - start;
                 if (start + len > F512_PS_STRIDE) {  // keep the padded read inside the row
@@ -866,7 +973,7 @@ static inline int fast512_plan_init(dsp_plan* p, const dsp_plan_desc* d, const i
                     lead += shift;
                 }
                 for (int s2 = 0; s2 < d->h_mel_count[j]; ++s2)
-                    melw[(size_t)c * melw_row + pos + lead + s2] = d->h_mel_weights[mel_off[j] + s2] * (1.0f / 2048.0f);
+                    melw[(size_t)c * melw_row + pos + lead + s2] = d->h_mel_weights[mel_off[j] + s2] * 2097152.0f;  // 2^32 / 2048
             }
             memcpy(&mels[(size_t)i * 8 + c], &start, 4);
             pos += len;
@@ -874,14 +981,15 @@ static inline int fast512_plan_init(dsp_plan* p, const dsp_plan_desc* d, const i
     }
     auto pad64 = [](size_t n) { return (n + 63) / 64 * 64; };
     const size_t o_tw1 = 512, o_dct = o_tw1 + tw1.size(), o_melw = pad64(o_dct + dct.size());
-    const size_t o_mels = o_melw + melw.size();
-    const size_t total = pad64(o_mels + mels.size());
+    const size_t o_mels = o_melw + melw.size(), o_bias = o_mels + mels.size();
+    const size_t total = pad64(o_bias + bias.size());
     std::vector<float> blob(total, 0.f);
     memcpy(blob.data(), win.data(), 512 * 4);
     memcpy(blob.data() + o_tw1, tw1.data(), tw1.size() * 4);
     memcpy(blob.data() + o_dct, dct.data(), dct.size() * 4);
     memcpy(blob.data() + o_melw, melw.data(), melw.size() * 4);
     memcpy(blob.data() + o_mels, mels.data(), mels.size() * 4);
+    memcpy(blob.data() + o_bias, bias.data(), bias.size() * 4);
     if (hipMalloc(reinterpret_cast<void**>(&fp->d_tables), total * 4) != hipSuccess ||
         hipMemcpy(fp->d_tables, blob.data(), total * 4, hipMemcpyHostToDevice) != hipSuccess) {
         delete fp;
@@ -890,12 +998,14 @@ static inline int fast512_plan_init(dsp_plan* p, const dsp_plan_desc* d, const i
     fp->P.tables = fp->d_tables;
     fp->P.tab_floats = (int32_t)total;
     fp->P.off_tw1 = (int32_t)o_tw1; fp->P.off_dct = (int32_t)o_dct;
-    fp->P.off_melw = (int32_t)o_melw; fp->P.off_mels = (int32_t)o_mels; fp->P.melw_row = melw_row;
+    fp->P.off_melw = (int32_t)o_melw; fp->P.off_mels = (int32_t)o_mels; fp->P.off_bias = (int32_t)o_bias;
+    fp->P.melw_row = melw_row;
     fp->P.L = L; fp->P.S = d->frame_step; fp->P.M = M; fp->P.C = C;
     fp->P.append_energy = d->append_energy ? 1 : 0;
     fp->P.preemph = d->preemph;
     fp->P.span_vec = ((variant == 2 ? span32 : span25) + 3) / 4;
     fp->variant = variant;
+    fp->caps = caps;
     p->d_fast = fp;
     return DSP_OK;
 }
@@ -921,7 +1031,7 @@ static inline bool fast512_applicable(const dsp_plan* p, const BatchGeom& bg, co
     return bg.total_frames / 8 + bg.n_utt <= 0x3fffffff;
 }
 
-template <int NROWS, int NI, int NC, int NSTAGE, int DTYPE, bool RAGGED>
+template <int NROWS, int NI, int CAPS, int NSTAGE, int DTYPE, bool RAGGED>
 static int fast512_launch_k(const F512Params& P, const void* d_wave, const BatchGeom& bg, float* d_out,
                             int64_t ld_out, int64_t groups_bound, hipStream_t st) {
     const size_t lds = ((size_t)P.tab_floats + (size_t)F512_WAVES * F512_WAVE_FLOATS) * sizeof(float);
@@ -937,7 +1047,7 @@ static int fast512_launch_k(const F512Params& P, const void* d_wave, const Batch
             blocks = cap;       // every CU fully occupied; the partial last round is dealt wave-major
         }
     }
-    auto k = mfcc512_kernel<NROWS, NI, NC, NSTAGE, DTYPE, F512_WAVES, RAGGED>;
+    auto k = mfcc512_kernel<NROWS, NI, CAPS, NSTAGE, DTYPE, F512_WAVES, RAGGED>;
     static size_t granted[DSP_MAX_DEVICES] = {};  // dynamic-LDS limit already raised, per device
     if (dsp_ensure_dynamic_lds((const void*)k, lds, granted) != 0) return DSP_EHIP;
     k<<<(int)blocks, 64 * F512_WAVES, lds, st>>>(P, bg, d_wave, d_out, ld_out);
@@ -951,7 +1061,7 @@ struct DspRaggedTables {
     int shift = 0;                  // 3: NFFT=512 kernel (8 frames per wave), 2: NFFT=1536 kernel
 };
 
-template <int NROWS, int NI, int NC, int NSTAGE>
+template <int NROWS, int NI, int CAPS, int NSTAGE>
 static int fast512_launch_t(F512Params P, const void* d_wave, int dtype, const BatchGeom& bg, float* d_out,
                             int64_t ld_out, hipStream_t st, const DspRaggedTables* pre = nullptr) {
     if (bg.uniform_samples > 0) {
@@ -970,8 +1080,8 @@ static int fast512_launch_t(F512Params P, const void* d_wave, int dtype, const B
             P.total_groups = (bg.total_frames + 7) / 8;
         }
         if (dtype == DSP_WAVE_I16)
-            return fast512_launch_k<NROWS, NI, NC, NSTAGE, DSP_WAVE_I16, false>(P, d_wave, bg, d_out, ld_out, P.total_groups, st);
-        return fast512_launch_k<NROWS, NI, NC, NSTAGE, DSP_WAVE_F32, false>(P, d_wave, bg, d_out, ld_out, P.total_groups, st);
+            return fast512_launch_k<NROWS, NI, CAPS, NSTAGE, DSP_WAVE_I16, false>(P, d_wave, bg, d_out, ld_out, P.total_groups, st);
+        return fast512_launch_k<NROWS, NI, CAPS, NSTAGE, DSP_WAVE_F32, false>(P, d_wave, bg, d_out, ld_out, P.total_groups, st);
     }
     // ragged: build the group tables in a pooled, event-guarded workspace (no host sync)
     const int64_t bound = bg.total_frames / 8 + bg.n_utt;  // >= sum ceil(T_b / 8)
@@ -991,9 +1101,9 @@ static int fast512_launch_t(F512Params P, const void* d_wave, int dtype, const B
     }
     int rc;
     if (dtype == DSP_WAVE_I16)
-        rc = fast512_launch_k<NROWS, NI, NC, NSTAGE, DSP_WAVE_I16, true>(P, d_wave, bg, d_out, ld_out, bound, st);
+        rc = fast512_launch_k<NROWS, NI, CAPS, NSTAGE, DSP_WAVE_I16, true>(P, d_wave, bg, d_out, ld_out, bound, st);
     else
-        rc = fast512_launch_k<NROWS, NI, NC, NSTAGE, DSP_WAVE_F32, true>(P, d_wave, bg, d_out, ld_out, bound, st);
+        rc = fast512_launch_k<NROWS, NI, CAPS, NSTAGE, DSP_WAVE_F32, true>(P, d_wave, bg, d_out, ld_out, bound, st);
     if (w != nullptr && dsp_workspace_pool().release(w, st) != 0 && rc == DSP_OK) rc = DSP_EHIP;
     return rc;
 }
@@ -1002,7 +1112,9 @@ static inline int fast512_launch(const dsp_plan* p, const void* d_wave, int dtyp
                                  float* d_out, int64_t ld_out, hipStream_t st, const DspRaggedTables* pre = nullptr) {
     const Fast512Plan* fp = static_cast<const Fast512Plan*>(p->d_fast);
     // exact instantiations for the common shapes, a padded catch-all otherwise (chosen at plan init)
-    if (fp->variant == 0) return fast512_launch_t<25, 4, 13, 6>(fp->P, d_wave, dtype, bg, d_out, ld_out, st, pre);
-    if (fp->variant == 1) return fast512_launch_t<25, 5, 13, 6>(fp->P, d_wave, dtype, bg, d_out, ld_out, st, pre);
-    return fast512_launch_t<32, 8, 16, 9>(fp->P, d_wave, dtype, bg, d_out, ld_out, st, pre);
+    if (fp->variant == 0 && fp->caps == 2) return fast512_launch_t<25, 4, 2, 6>(fp->P, d_wave, dtype, bg, d_out, ld_out, st, pre);
+    if (fp->variant == 0) return fast512_launch_t<25, 4, 0, 6>(fp->P, d_wave, dtype, bg, d_out, ld_out, st, pre);
+    if (fp->variant == 1 && fp->caps == 1) return fast512_launch_t<25, 5, 1, 6>(fp->P, d_wave, dtype, bg, d_out, ld_out, st, pre);
+    if (fp->variant == 1) return fast512_launch_t<25, 5, 0, 6>(fp->P, d_wave, dtype, bg, d_out, ld_out, st, pre);
+    return fast512_launch_t<32, 8, 0, 9>(fp->P, d_wave, dtype, bg, d_out, ld_out, st, pre);
 }

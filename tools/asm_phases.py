@@ -8,7 +8,7 @@ import sys
 
 ROOT = __file__.rsplit('/', 2)[0]
 src = sys.argv[1] if len(sys.argv) > 1 else '/tmp/f512_stamps.s'
-want = sys.argv[2] if len(sys.argv) > 2 else 'mfcc512_kernelILi25ELi5ELi13ELi6ELi0ELi8ELb0E'
+want = sys.argv[2] if len(sys.argv) > 2 else 'mfcc512_kernelILi25ELi5ELi1ELi6ELi0ELi8ELb0E'
 if len(sys.argv) <= 1:
     subprocess.run(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', f'-I{ROOT}/include',
                     '-I.', '-ffp-contract=fast', '-fno-gpu-rdc', '-fno-slp-vectorize', '-DF512_STAMPS', '-S',
