@@ -127,7 +127,7 @@ DspWorkspace* fused_kernel_view(BatchGeom& bg, const void*& d_wave, int wave_dty
     const uintptr_t mis = addr % (4 * elem);               // bytes past the previous aligned vector
     const bool odd_dense = bg.uniform_samples > 0 && (bg.uniform_samples % 4) != 0;
     if ((mis == 0 && !odd_dense) || (mis % elem) != 0) return nullptr;
-    DspWorkspace* w = dsp_workspace_pool().acquire(2 * ((size_t)bg.n_utt + 1) * sizeof(int64_t));
+    DspWorkspace* w = dsp_workspace_pool().acquire(2 * ((size_t)bg.n_utt + 1) * sizeof(int64_t), st);
     if (!w) return nullptr;
     int64_t* so = static_cast<int64_t*>(w->ptr);
     int64_t* fo = so + bg.n_utt + 1;
@@ -151,6 +151,11 @@ int dsp_abi_version(void) { return DSP_ABI_VERSION; }
 
 int dsp_debug_force_generic(int on) {
     g_force_generic = on ? 1 : 0;
+    return DSP_OK;
+}
+
+int dsp_debug_pool_stats(long long* n_buffers, long long* bytes) {
+    dsp_workspace_pool().stats(n_buffers, bytes);
     return DSP_OK;
 }
 
@@ -448,7 +453,7 @@ int dsp_delta_batch(const float* d_in, int64_t ld_in, const int64_t* d_frame_off
         const int64_t bound = n_frames_total / DT_TILE + n_utt;
         if (bound > 0x7fffffff) return fail(DSP_EINVAL, "too many delta tiles");
         hipStream_t st = (hipStream_t)stream;
-        DspWorkspace* w = dsp_workspace_pool().acquire(((size_t)n_utt + 1) * sizeof(int64_t));
+        DspWorkspace* w = dsp_workspace_pool().acquire(((size_t)n_utt + 1) * sizeof(int64_t), st);
         if (!w) return fail(DSP_EHIP, "workspace allocation failed");
         int64_t* tile_off = static_cast<int64_t*>(w->ptr);
         prefix_ceil_kernel<<<1, 1024, 0, st>>>(d_frame_offsets, n_utt, DT_SHIFT, tile_off);
@@ -478,6 +483,11 @@ int dsp_mfcc_delta_batch(const dsp_plan* plan, const void* d_wave, int wave_dtyp
 #endif
     const int C = plan->C;
     if (C <= 0) return fail(DSP_EINVAL, "plan has no mel/DCT tables");
+    if (!d_out) return fail(DSP_EINVAL, "plan/d_out is NULL");
+    {   // validate before the first launch or workspace acquire (the table kernels read the offset arrays)
+        const int grc = check_geom(d_wave, wave_dtype, d_sample_offsets, d_frame_offsets, n_utt, n_frames_total, uniform_samples);
+        if (grc != DSP_OK) return grc;
+    }
     int64_t uniform_frames = 0;
     if (uniform_samples > 0) dsp_frame_count(uniform_samples, plan->L, plan->S, &uniform_frames);
     hipStream_t st = (hipStream_t)stream;
@@ -505,8 +515,8 @@ int dsp_mfcc_delta_batch(const dsp_plan* plan, const void* d_wave, int wave_dtyp
             const size_t tile_bytes = ragged ? pad256(((size_t)n_utt + 1) * sizeof(int64_t)) : 0;
             const size_t goff_bytes = ragged && gshift ? pad256(((size_t)n_utt + 1) * sizeof(int32_t)) : 0;
             const size_t gutt_bytes = ragged && gshift ? pad256((size_t)gbound * sizeof(int32_t)) : 0;
-            DspWorkspace* w = dsp_workspace_pool().acquire(tile_bytes + goff_bytes + gutt_bytes + scratch_bytes);
-            if (!w) return fail(DSP_EHIP, "workspace allocation failed");
+            DspWorkspace* w = dsp_workspace_pool().acquire(tile_bytes + goff_bytes + gutt_bytes + scratch_bytes, st);
+            if (w) {
             char* wp = static_cast<char*>(w->ptr);
             int64_t* tile_off = ragged ? reinterpret_cast<int64_t*>(wp) : nullptr;
             DspRaggedTables pre;
@@ -538,6 +548,8 @@ int dsp_mfcc_delta_batch(const dsp_plan* plan, const void* d_wave, int wave_dtyp
             }
             if (dsp_workspace_pool().release(w, st) != 0 && rc == DSP_OK) rc = fail(DSP_EHIP, "workspace release failed");
             return rc;
+            }
+            // no scratch to be had (device memory exhausted): the in-place form below needs none
         }
     }
     int rc = dsp_features_batch(plan, d_wave, wave_dtype, d_sample_offsets, d_frame_offsets, n_utt,

@@ -747,7 +747,7 @@ static int fast1536_launch_t(F1536Params P, const void* d_wave, int dtype, const
         P.group_utt = pre->group_utt;
     } else {
         const size_t ws_bytes = ((size_t)bg.n_utt + 1 + (size_t)bound) * sizeof(int32_t);
-        w = dsp_workspace_pool().acquire(ws_bytes);
+        w = dsp_workspace_pool().acquire(ws_bytes, st);
         if (!w) return DSP_EHIP;
         int32_t* group_off = static_cast<int32_t*>(w->ptr);
         int32_t* group_utt = group_off + bg.n_utt + 1;

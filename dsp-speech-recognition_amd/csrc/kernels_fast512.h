@@ -29,7 +29,7 @@
 
 #define F512_WAVE_FLOATS 2112  // per-wave LDS: 8 frames x 264 floats (staging / exchange alias it)
 #define F512_PS_STRIDE 264     // == 8 (mod 32): the 8 frames' rows start on distinct bank octets
-#define F512_MAX_NI 8
+#define F512_MAX_NI 6   // filter iterations of the catch-all instantiation: up to 48 filters
 #ifndef F512_WAVES
 #define F512_WAVES 8
 #endif
@@ -322,6 +322,20 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
     // The last, partial round is dealt wave-major instead (group base + b + gridDim * w): its groups
     // go to wave 0 of every workgroup first, so no SIMD carries more than one group above the average.
     const int nfull = total_groups / gstride;
+#if defined(F512_PRIO_EXTRA) || defined(F512_STAGGER)
+    {   // experiments (tools/build_variants.sh): waves that carry a group of the partial last round are the critical path
+        const bool has_extra = nfull * gstride + (int)blockIdx.x + (int)gridDim.x * wid < total_groups;
+#ifdef F512_PRIO_EXTRA
+        if (has_extra) __builtin_amdgcn_s_setprio(F512_PRIO_EXTRA);
+#endif
+#ifdef F512_STAGGER
+        if (!has_extra) {
+            const int steps = (wid >> 2) + 2 * (((int)blockIdx.x / (int)(gridDim.x / 2)) & 1);
+            for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(F512_STAGGER);
+        }
+#endif
+    }
+#endif
 #ifdef F512_STAMPS
     unsigned int stamp_acc_[F512_NSTAMP] = {};
     unsigned int stamp_prev_ = f512_clock();
@@ -359,20 +373,38 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         //      pre-emphasis, zero fill outside the utterance. ----
         if (fast_stage) {
             {
+                asm volatile("; F512_FAST_STAGE (tools/asm_count.py counts from here to the loop's back edge)");
                 F512Raw<DTYPE> raw[NSTAGE];
+                float prev[NSTAGE];
                 const int64_t e0 = g0 + 4 * lane;
 #pragma unroll
                 for (int r = 0; r < NSTAGE; ++r)
                     raw[r] = RAGGED ? f512_load_raw_unaligned<DTYPE>(wave, e0 + 256 * r) : f512_load_raw<DTYPE>(wave, e0 + 256 * r);
-                float left = base > 0 ? dsp_load_sample<DTYPE>(wave, g0 - 1) : 0.f;
+                // the sample before each vector: one more (cache-resident) dword per lane instead of a DPP shift,
+                // a v_readlane and a move per vector
+#ifndef F512_STAGE_DPP
+#pragma unroll
+                for (int r = 1; r < NSTAGE; ++r) prev[r] = dsp_load_sample<DTYPE>(wave, e0 + 256 * r - 1);
+#endif
+                // an utterance's first sample is not filtered (sigproc.py:185): y[0] = x[0] - c * 0
+                if (base > 0) prev[0] = dsp_load_sample<DTYPE>(wave, e0 - 1);
+                else prev[0] = lane > 0 ? dsp_load_sample<DTYPE>(wave, e0 - 1) : 0.f;
+#ifdef F512_STAGE_DPP   // A/B: the round-2 form (previous sample through DPP wave_shr + v_readlane)
+                float left = prev[0];
 #pragma unroll
                 for (int r = 0; r < NSTAGE; ++r) {
                     float x[4];
                     f512_unpack<DTYPE>(raw[r], x);
-                    const float prev = f512_shift_in(x[3], left);   // sample before x[0]
+                    prev[r] = f512_shift_in(x[3], left);
                     left = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[3]), 63));
+                }
+#endif
+#pragma unroll
+                for (int r = 0; r < NSTAGE; ++r) {
+                    float x[4];
+                    f512_unpack<DTYPE>(raw[r], x);
                     float4 y;
-                    y.x = fmaf(-P.preemph, prev, x[0]);
+                    y.x = fmaf(-P.preemph, prev[r], x[0]);
                     y.y = fmaf(-P.preemph, x[0], x[1]);
                     y.z = fmaf(-P.preemph, x[1], x[2]);
                     y.w = fmaf(-P.preemph, x[2], x[3]);
@@ -846,6 +878,9 @@ static inline void f512_build_group_tables(const int64_t* frame_off, int32_t n_u
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// More than 48 filters on 257 bins means filters of one or two bins (the first one is the DC bin alone at 16 kHz):
+// their logarithms amplify the fp32 noise floor of single bins, where this kernel measured 1.5e-4 against the
+// generic kernel's 5e-5 on the same data (profiles/r2_parity_measured.json) -- such plans stay on the generic kernel.
 static inline bool fast512_shape_ok(const dsp_plan_desc* d) {
     return d->nfft == 512 && d->frame_len <= 512 && (d->frame_step % 2) == 0 && d->frame_step >= 2 &&
            7 * d->frame_step + 512 + 16 <= F512_WAVE_FLOATS && d->nfilt >= 1 &&
@@ -1070,9 +1105,11 @@ static int fast512_launch_t(F512Params P, const void* d_wave, int dtype, const B
         // Flat grouping (groups of 8 cut from the flat frame sequence, a group may span the seam between two
         // utterances) wastes no frame slots at the end of an utterance: 99 frames are 13 groups of 8 otherwise
         // (5 % idle slots).  Needs vector-aligned hops and room for the seam's second segment in the wave buffer.
-        const int seam = (P.L - P.S + 3) / 4 * 4;
+        // (the seam is as long as the samples pass 1 READS per frame, 16 x NROWS >= L: a frame's rows beyond L meet a
+        // zero window, but 0 x NaN of the next utterance's samples would still poison the frame)
+        const int seam = (16 * NROWS - P.S + 3) / 4 * 4;
         static const bool no_flat = getenv("DSP_F512_NOFLAT") != nullptr;   // A/B switch for tools/kbench.py
-        if (!no_flat && (P.S % 4) == 0 && P.L > P.S && bg.uniform_frames >= 8 && (bg.uniform_frames % 8) != 0 &&
+        if (!no_flat && (P.S % 4) == 0 && P.L > P.S && 16 * NROWS > P.S && bg.uniform_frames >= 8 && (bg.uniform_frames % 8) != 0 &&
             7 * P.S + 16 * NROWS + seam + 4 <= F512_WAVE_FLOATS && 7 * P.S + 16 * NROWS + seam <= 256 * (NSTAGE + 1) &&
             bg.total_frames + 8 <= 0x3fffffff) {
             P.flat = 1;
@@ -1091,7 +1128,7 @@ static int fast512_launch_t(F512Params P, const void* d_wave, int dtype, const B
         P.group_utt = pre->group_utt;
     } else {
         const size_t ws_bytes = ((size_t)bg.n_utt + 1 + (size_t)bound) * sizeof(int32_t);
-        w = dsp_workspace_pool().acquire(ws_bytes);
+        w = dsp_workspace_pool().acquire(ws_bytes, st);
         if (!w) return DSP_EHIP;
         int32_t* group_off = static_cast<int32_t*>(w->ptr);
         int32_t* group_utt = group_off + bg.n_utt + 1;
@@ -1116,5 +1153,5 @@ static inline int fast512_launch(const dsp_plan* p, const void* d_wave, int dtyp
     if (fp->variant == 0) return fast512_launch_t<25, 4, 0, 6>(fp->P, d_wave, dtype, bg, d_out, ld_out, st, pre);
     if (fp->variant == 1 && fp->caps == 1) return fast512_launch_t<25, 5, 1, 6>(fp->P, d_wave, dtype, bg, d_out, ld_out, st, pre);
     if (fp->variant == 1) return fast512_launch_t<25, 5, 0, 6>(fp->P, d_wave, dtype, bg, d_out, ld_out, st, pre);
-    return fast512_launch_t<32, 8, 0, 9>(fp->P, d_wave, dtype, bg, d_out, ld_out, st, pre);
+    return fast512_launch_t<32, F512_MAX_NI, 0, 9>(fp->P, d_wave, dtype, bg, d_out, ld_out, st, pre);
 }

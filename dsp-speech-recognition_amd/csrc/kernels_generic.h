@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64 * DSP_GEN_WAVES) void features_generic_kernel(
     float2* bufB = bufA + N2;
 
     // ragged batches: bg.total_frames may be an upper bound (device-built layouts), the table holds the truth
-    const int64_t total_frames = bg.frame_off ? bg.frame_off[bg.n_utt] : bg.total_frames;
+    const int64_t total_frames = bg.uniform_frames > 0 ? bg.total_frames : bg.frame_off[bg.n_utt];   // the table is read for ragged geometry only
     const int64_t n_tiles = (total_frames + DSP_GEN_WAVES - 1) / DSP_GEN_WAVES;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         int64_t g = tile * DSP_GEN_WAVES + wid;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(64 * DSP_GEN_WAVES) void features_generic_kernel(
 __global__ __launch_bounds__(256) void delta_kernel(const float* __restrict__ in, int64_t ld_in, BatchGeom bg,
                                                     int32_t D, int32_t N, float inv_den, float* __restrict__ out,
                                                     int64_t ld_out, float* __restrict__ out_dd, int64_t ld_dd) {
-    const int64_t total = (bg.frame_off ? bg.frame_off[bg.n_utt] : bg.total_frames) * D;
+    const int64_t total = (bg.uniform_frames > 0 ? bg.total_frames : bg.frame_off[bg.n_utt]) * D;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int64_t g = idx / D;
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void vad_features_kernel(const void* __restric
                                                            int32_t S, int32_t use_sq, double* __restrict__ amp_sum,
                                                            int32_t* __restrict__ zcr) {
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t total_frames = bg.frame_off ? bg.frame_off[bg.n_utt] : bg.total_frames;   // ragged: the table is the truth
+    const int64_t total_frames = bg.uniform_frames > 0 ? bg.total_frames : bg.frame_off[bg.n_utt];   // ragged: the table is the truth
     const int64_t n_tiles = (total_frames + 3) / 4;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t g = tile * 4 + wid;

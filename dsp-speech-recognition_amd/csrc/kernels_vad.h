@@ -520,7 +520,7 @@ static int vad_tile_launch_t(VadParams P, const BatchGeom& bg, const void* d_wav
     }
     const int64_t bound = bg.total_frames / FR + bg.n_utt;
     const size_t ws_bytes = ((size_t)bg.n_utt + 1 + (size_t)bound) * sizeof(int32_t);
-    DspWorkspace* w = dsp_workspace_pool().acquire(ws_bytes);
+    DspWorkspace* w = dsp_workspace_pool().acquire(ws_bytes, st);
     if (!w) return DSP_EHIP;
     int32_t* group_off = static_cast<int32_t*>(w->ptr);
     int32_t* group_utt = group_off + bg.n_utt + 1;

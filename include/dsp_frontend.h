@@ -104,6 +104,8 @@ int dsp_plan_has_fast_path(const dsp_plan* plan);
    specialised one applies (thread-local flag: other threads are unaffected; the kernels are independent
    implementations and must agree) */
 int dsp_debug_force_generic(int on);
+/* testing aid: device workspaces (index tables, cepstra scratch) the library's pool currently holds */
+int dsp_debug_pool_stats(long long* n_buffers, long long* bytes);
 
 /* ---- the hot path -------------------------------------------------------------------------- */
 /*

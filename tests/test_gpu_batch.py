@@ -121,6 +121,64 @@ def test_ragged_calls_queued_back_to_back(plan):
             assert np.array_equal(got, jobs[j][2]), (rep, j)
 
 
+def test_workspace_pool_stays_bounded_when_the_host_queues_ahead(plan):
+    """dsp_mfcc_delta_batch leases its dense-cepstra scratch from the workspace pool.  A host
+    that queues hundreds of steps without synchronising must not grow the pool with the queue depth: work on ONE
+    stream reuses the stream's last buffer at once, and three streams need three buffers."""
+    import ctypes as C
+    import torch
+    from features import _native as nat
+    lib = nat.load()
+    B = 256
+    waves = _batch(77, B)
+    lay = plan.layout(waves)
+    dev = torch.device('cuda', 0)
+    d_wave = torch.from_numpy(waves).to(dev)
+    streams = [torch.cuda.Stream(dev) for _ in range(3)]
+    outs = [torch.empty((B * 99, 39), device=dev) for _ in streams]
+    torch.cuda.synchronize()
+    for k, s in enumerate(streams):                      # warm up: one buffer per stream
+        plan.run_raw(d_wave.data_ptr(), nat.WAVE_F32, lay, outs[k].data_ptr(), 2, s.cuda_stream)
+    torch.cuda.synchronize()
+    n0, b0 = C.c_longlong(0), C.c_longlong(0)
+    nat.check(lib.dsp_debug_pool_stats(C.byref(n0), C.byref(b0)))
+    for i in range(600):                                 # ~25 ms of queued device work, no host sync
+        k = i % 3
+        plan.run_raw(d_wave.data_ptr(), nat.WAVE_F32, lay, outs[k].data_ptr(), 2, streams[k].cuda_stream)
+    n1, b1 = C.c_longlong(0), C.c_longlong(0)
+    nat.check(lib.dsp_debug_pool_stats(C.byref(n1), C.byref(b1)))
+    # (the warm-up calls may have shared buffers whose earlier users had finished: allow one new buffer per stream)
+    assert n1.value <= n0.value + 3 and b1.value <= b0.value + (8 << 20), (n0.value, b0.value, n1.value, b1.value)
+    for i in range(600):                                 # ... and from then on nothing
+        k = i % 3
+        plan.run_raw(d_wave.data_ptr(), nat.WAVE_F32, lay, outs[k].data_ptr(), 2, streams[k].cuda_stream)
+    n2, b2 = C.c_longlong(0), C.c_longlong(0)
+    nat.check(lib.dsp_debug_pool_stats(C.byref(n2), C.byref(b2)))
+    torch.cuda.synchronize()
+    assert (n2.value, b2.value) == (n1.value, b1.value), (n1.value, b1.value, n2.value, b2.value)
+    ref, _ = plan.mfcc_batch(waves, delta_n=2)
+    for o in outs:
+        assert np.array_equal(o.cpu().numpy(), ref)
+
+
+def test_a_nan_clip_does_not_leak_into_its_neighbours():
+    """with flat grouping a frame group may span two utterances of a dense batch.  Pass 1 reads
+    16 x NROWS samples per frame (400 for L <= 400), beyond L they meet a zero window -- but 0 x NaN is NaN, so
+    the next utterance's samples must not sit there.  A clean clip's rows must not depend on its neighbours."""
+    from features.batch import FeaturePlan
+    cfg = dict(CFG)
+    cfg.update(winlen=0.02, winstep=0.01)                # L = 320 < 400: rows 20..24 of every frame are padding
+    plan = FeaturePlan(winfunc=np.hamming, **cfg)
+    waves = _batch(78, 6, 16000)
+    clean, _ = plan.mfcc_batch(waves, delta_n=2)
+    bad = waves.copy()
+    bad[1, :] = np.nan
+    bad[3, :400] = np.inf
+    got, fo = plan.mfcc_batch(bad, delta_n=2)
+    for b in (0, 2, 4, 5):
+        assert np.array_equal(got[fo[b]:fo[b + 1]], clean[fo[b]:fo[b + 1]]), b
+
+
 def test_parseval_full_size():
     """Oracle-free property: sum_n frame[n]^2 == pspec[0] + 2 sum_{0<k<256} pspec[k] + pspec[256]
      on an 8 s signal through the framesig / powspec kernels."""
@@ -238,11 +296,12 @@ def test_config4_vad_trim_mfcc_pipeline(unit_variance):
 
 @pytest.mark.parametrize('cfg', [
     dict(winlen=0.03, winstep=0.01, nfilt=48, numcep=16),      # L=480 -> 30 rows, 6 mel groups: catch-all kernel
-    dict(winlen=0.032, winstep=0.008, nfilt=64, numcep=13),    # L=512 (= NFFT), S=128, 8 mel groups
+    dict(winlen=0.032, winstep=0.008, nfilt=64, numcep=13),    # L=512 (= NFFT), S=128; 64 filters: generic kernel
+    dict(winlen=0.032, winstep=0.008, nfilt=47, numcep=13),    # L=512, odd filter count, 6 mel iterations
     dict(winlen=0.02, winstep=0.005, nfilt=26, numcep=12),     # L=320, S=80: 26-filter instantiation
     dict(winlen=0.025, winstep=0.0101, nfilt=40, numcep=13),   # S=162 (even, not /4)
     dict(winlen=0.025, winstep=0.01, nfilt=40, numcep=13, lowfreq=300, highfreq=3400, preemph=0.0),
-], ids=['L480_M48_C16', 'L512_M64', 'L320_M26_C12', 'S162', 'band_nopre'])
+], ids=['L480_M48_C16', 'L512_M64', 'L512_M47', 'L320_M26_C12', 'S162', 'band_nopre'])
 @pytest.mark.parametrize('dtype', [np.float32, np.int16])
 def test_fast_kernel_instantiations(cfg, dtype):
     """Every <rows, mel groups, cepstra> instantiation of the specialised kernel, dense and ragged,
@@ -252,10 +311,11 @@ def test_fast_kernel_instantiations(cfg, dtype):
     full = dict(samplerate=16000, nfft=512, lowfreq=0, highfreq=None, preemph=0.97, ceplifter=22, appendEnergy=True)
     full.update(cfg)
     plan = FeaturePlan(winfunc=np.hamming, **full)
-    assert nat.load().dsp_plan_has_fast_path(plan.plan.handle) == 1
-    # 64 filters on a 257-bin spectrum: the lowest ones are 1-2 bins wide and their logs amplify the
-    # fp32 FFT noise floor (the generic kernel shows 5.5e-5 on the same data)
-    tol = 3e-4 if full['nfilt'] >= 64 else TOL      # measured 1.51e-4 at 64 filters (parity_measured.json): 2x
+    # 64 filters on a 257-bin spectrum: the lowest ones are 1-2 bins wide (the first is the DC bin alone) and their
+    # logs amplify the fp32 noise floor of single bins; the fused kernel measured 1.5e-4 there, the generic one
+    # 5e-5, so plans with more than 48 filters are served by the generic kernel and every plan meets the plain bar
+    assert nat.load().dsp_plan_has_fast_path(plan.plan.handle) == (1 if full['nfilt'] <= 48 else 0)
+    tol = TOL
     dense = _batch(51, 24, 8000, dtype=dtype)
     out, fo = plan.mfcc_batch(dense, delta_n=2)
     lens = [8000, 513, 4097, 1, 7999, 12001, 640]

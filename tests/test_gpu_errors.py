@@ -43,6 +43,11 @@ def test_status_codes_and_messages(env):
     # unsupported sample type; ragged batch without offsets
     assert lib.dsp_features_batch(h, x.ptr, 7, None, None, 1, 99, 16000, nat.OUT_MFCC, out.ptr, 0, None, None) == -1
     assert lib.dsp_features_batch(h, x.ptr, nat.WAVE_F32, None, None, 1, 99, 0, nat.OUT_MFCC, out.ptr, 0, None, None) == -1
+    # the fused MFCC + delta entry point validates before its first launch (a NULL d_out used to reach a kernel)
+    assert lib.dsp_mfcc_delta_batch(h, x.ptr, nat.WAVE_F32, None, None, 1, 99, 16000, 2, None, None) == -1
+    assert 'NULL' in _msg(lib)
+    assert lib.dsp_mfcc_delta_batch(h, None, nat.WAVE_F32, None, None, 1, 99, 16000, 2, out.ptr, None) == -1
+    assert lib.dsp_mfcc_delta_batch(h, x.ptr, nat.WAVE_F32, None, None, 0, 99, 16000, 2, out.ptr, None) == -1
     # delta: N < 1 is the reference's ValueError (base.py:71-72)
     assert lib.dsp_delta_batch(out.ptr, 39, None, 1, 99, 99, 13, 0, out.ptr, 39, None, 0, None) == -1
     assert 'N must be an integer >= 1' in _msg(lib)
