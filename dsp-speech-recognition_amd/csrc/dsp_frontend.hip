@@ -549,7 +549,8 @@ int dsp_mfcc_delta_batch(const dsp_plan* plan, const void* d_wave, int wave_dtyp
             if (dsp_workspace_pool().release(w, st) != 0 && rc == DSP_OK) rc = fail(DSP_EHIP, "workspace release failed");
             return rc;
             }
-            // no scratch to be had (device memory exhausted): the in-place form below needs none
+            // no scratch to be had (device memory exhausted, or `stream` is being captured into a HIP graph): the
+            // in-place form below needs none -- same values, 52-byte partial row writes instead of whole lines
         }
     }
     int rc = dsp_features_batch(plan, d_wave, wave_dtype, d_sample_offsets, d_frame_offsets, n_utt,

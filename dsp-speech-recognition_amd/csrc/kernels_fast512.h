@@ -322,26 +322,17 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
     // The last, partial round is dealt wave-major instead (group base + b + gridDim * w): its groups
     // go to wave 0 of every workgroup first, so no SIMD carries more than one group above the average.
     const int nfull = total_groups / gstride;
-#if defined(F512_PRIO_EXTRA) || defined(F512_STAGGER)
-    {   // experiments (tools/build_variants.sh): waves that carry a group of the partial last round are the critical path
-        const bool has_extra = nfull * gstride + (int)blockIdx.x + (int)gridDim.x * wid < total_groups;
-#ifdef F512_PRIO_EXTRA
-        if (has_extra) __builtin_amdgcn_s_setprio(F512_PRIO_EXTRA);
-#endif
-#ifdef F512_STAGGER
-        if (!has_extra) {
-            const int steps = (wid >> 2) + 2 * (((int)blockIdx.x / (int)(gridDim.x / 2)) & 1);
-            for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(F512_STAGGER);
-        }
-#endif
-    }
-#endif
 #ifdef F512_STAMPS
     unsigned int stamp_acc_[F512_NSTAMP] = {};
     unsigned int stamp_prev_ = f512_clock();
     const unsigned int stamp_loop0_ = stamp_prev_;
 #endif
 
+#ifdef F512_TOUCH_NEXT
+    float touch_[NSTAGE];   // one dword per 16-byte vector of the NEXT group's samples: pulls them into L2 / the vector cache
+#pragma unroll
+    for (int q = 0; q < NSTAGE; ++q) touch_[q] = 0.f;
+#endif
     for (int r = 0; r <= nfull; ++r) {
         int G;
         if (r < nfull) {
@@ -504,6 +495,10 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
                 }
             }
         }
+#ifdef F512_TOUCH_NEXT
+#pragma unroll
+        for (int q = 0; q < NSTAGE; ++q) asm volatile("" :: "v"(touch_[q]));
+#endif
         F512_FENCE();
         F512_STAMP(1);
 
@@ -677,6 +672,24 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         F512_FENCE();
         F512_STAMP(7);
 
+#ifdef F512_TOUCH_NEXT
+        if constexpr (!RAGGED) {
+            int Gn = -1;
+            if (r + 1 < nfull) Gn = (r + 1) * gstride + (int)blockIdx.x * WAVES + wid;
+            else if (r + 1 == nfull) Gn = nfull * gstride + (int)blockIdx.x + (int)gridDim.x * wid;
+            if (Gn >= 0 && Gn < total_groups) {
+                const F512Group gn = f512_locate<RAGGED>(P, bg, Gn);
+                const int64_t en = gn.s0 + (int64_t)gn.t0 * P.S + 4 * lane;
+                const int64_t lim = (int64_t)bg.n_utt * bg.uniform_samples - 4;
+#pragma unroll
+                for (int q = 0; q < NSTAGE; ++q) {
+                    int64_t idx = en + 256 * q;
+                    idx = idx < lim ? idx : lim;
+                    touch_[q] = dsp_load_sample<DTYPE>(wave, idx);
+                }
+            }
+        }
+#endif
         // ---- sparse mel triangles, log2.  Lane c owns one filter slot per iteration i; its weights sit in one LDS
         //      row, the spectrum bins of a filter are contiguous from a 16-byte aligned start, so both are read as
         //      b128 blocks of 4 taps.  Weights carry 2^21 = 2^32 / 2048; an all-zero filter gives log2(eps 2^32) = -20

@@ -6,6 +6,7 @@
 // buffer carries the stream of its last user and an event recorded behind that user:
 //   * a call on the SAME stream may take the buffer at once (stream order already protects it),
 //   * a call on another stream may take it once the event has completed,
+//   * a stream under HIP-graph capture gets none (see acquire),
 //   * otherwise a new buffer is allocated -- until the pool holds DSP_WS_POOL_CAP_MB (default 1024) MiB; past
 //     that, completed buffers are freed, and if that is not enough the call WAITS for the best-fitting buffer
 //     in flight instead of growing the pool (a host that queues thousands of steps ahead keeps a bounded pool).
@@ -19,6 +20,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <vector>
@@ -59,7 +61,20 @@ class DspWorkspacePool {
             return w;
         }
 #endif
+        {   // A stream that is being captured into a HIP graph gets nothing: event queries and allocations are
+            // not allowed there (hipErrorStreamCaptureUnsupported invalidates the capture), and a buffer baked into a
+            // graph would be reused by every replay behind the pool's back.  Callers fall back or report.
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+            if (cs != hipStreamCaptureStatusNone) return nullptr;
+        }
         std::lock_guard<std::mutex> lk(mu_);
+        static const bool dbg = getenv("DSP_WS_DEBUG") != nullptr;
+        if (dbg) {
+            fprintf(stderr, "[ws] acquire %zu B on stream %p; pool:", bytes, (void*)st);
+            for (DspWorkspace* w : all_) fprintf(stderr, " (%zu%s%s s=%p)", w->bytes, w->leased ? " leased" : "", w->used ? "" : " new", (void*)w->last_stream);
+            fprintf(stderr, "\n");
+        }
         // round up so that slightly larger batches reuse the buffer
         size_t want = 4096;
         while (want < bytes) want *= 2;
@@ -75,9 +90,13 @@ class DspWorkspacePool {
         best = nullptr;
         for (DspWorkspace* w : all_) {
             if (w->leased || w->device != dev || w->bytes < bytes || (best && w->bytes >= best->bytes)) continue;
-            if (w->used && w->last_stream != st && hipEventQuery(w->done) != hipSuccess) {  // still in flight (or error)
-                (void)hipGetLastError();
-                continue;
+            if (w->used && w->last_stream != st) {
+                const hipError_t qe = hipEventQuery(w->done);
+                if (qe != hipSuccess) {  // still in flight (or error)
+                    if (dbg) fprintf(stderr, "[ws]   query %zu B: %s\n", w->bytes, hipGetErrorName(qe));
+                    (void)hipGetLastError();
+                    continue;
+                }
             }
             best = w;
         }
