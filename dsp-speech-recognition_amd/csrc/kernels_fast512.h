@@ -47,6 +47,8 @@ struct F512Params {
     int32_t span_vec;      // ceil((7 S + L) / 4): 16-byte vectors staged per wave
     int32_t nb4[F512_MAX_NI];  // 16-byte blocks (4 taps) per filter iteration, the longest of its 8 slots
     int64_t groups_per_utt, total_groups;   // uniform batches
+    uint32_t t_magic, t_shift;               // x / uniform_frames   = (uint64) x * t_magic >> t_shift   for x < 2^30
+    uint32_t g_magic, g_shift;               // x / groups_per_utt, likewise
     int32_t flat;          // uniform batches: groups are cut from the FLAT frame sequence (a group may span two utterances)
     int32_t seam_off;      // ... then frames of the second utterance sit this many floats further into the LDS image
     const int32_t* group_off;                // ragged: [B+1] prefix of ceil(T_b / 8)
@@ -231,6 +233,17 @@ __device__ __forceinline__ float f512_shift_in(float v, float left) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(left), __float_as_int(v), 0x138, 0xF, 0xF, false));
 }
 
+// floor(x / d) for 0 <= x < 2^30 as a multiply and a shift: magic = ceil(2^(30 + l) / d), l = ceil(log2 d).
+static inline void f512_magic(uint32_t d, uint32_t& magic, uint32_t& shift) {
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    shift = 30 + l;
+    magic = (uint32_t)(((1ull << shift) + d - 1) / d);
+}
+__device__ __forceinline__ int f512_div(int x, uint32_t magic, uint32_t shift) {
+    return (int)(((uint64_t)(uint32_t)x * magic) >> shift);
+}
+
 // Where a frame group lives (all wave-uniform).
 struct F512Group {
     int utt, t0, T, nsamp;
@@ -255,12 +268,12 @@ __device__ __forceinline__ F512Group f512_locate(const F512Params& P, const Batc
         if (P.flat) {
             // groups of 8 cut from the flat frame sequence: no frame slot is wasted at the end of an utterance
             const int F0 = 8 * G;
-            g.utt = F0 / g.T;
+            g.utt = f512_div(F0, P.t_magic, P.t_shift);
             g.t0 = F0 - g.utt * g.T;
             g.nf1 = g.T - g.t0 < 8 ? g.T - g.t0 : 8;
         } else {
             const int gpu = (int)P.groups_per_utt;
-            g.utt = G / gpu;
+            g.utt = f512_div(G, P.g_magic, P.g_shift);
             g.t0 = (G - g.utt * gpu) * 8;
             g.nf1 = 8;
         }
@@ -284,30 +297,58 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
     const unsigned int stamp_entry_ = f512_clock();
     const unsigned int stamp_rt0_ = (unsigned int)__builtin_amdgcn_s_memrealtime();
 #endif
-    // Dense batches: touch the first group's samples before the tables are copied, so that the HBM latency of
-    // the wave's first loads overlaps the table copy (the data waits in L2 / the vector cache): at the start of
-    // a launch every wave is waiting for HBM at once and there is nothing else to run (45.9 -> 44.2 us).
-    float warm_ = 0.f;
-    if constexpr (!RAGGED) {
-        const int G0 = (int)blockIdx.x * WAVES + (tid >> 6);
-        if (G0 < (int)P.total_groups) {
-            const int64_t e = P.flat ? (int64_t)(8 * G0 / (int)bg.uniform_frames) * bg.uniform_samples +
-                                           (int64_t)(8 * G0 % (int)bg.uniform_frames) * P.S
-                                     : (int64_t)(G0 / (int)P.groups_per_utt) * bg.uniform_samples +
-                                           (int64_t)(G0 % (int)P.groups_per_utt) * 8 * P.S;
-            const int64_t lim = (int64_t)bg.n_utt * bg.uniform_samples - 4;
+    // Prologue.  The table loads are issued FIRST, then (dense batches) one dword per 16-byte vector of the wave's first
+    // group: the copy to LDS and the barrier wait for the tables only (vmcnt leaves the younger touches in flight),
+    // so the workgroup's eight waves are not coupled to the slowest of their first HBM fetches -- at the start of a
+    // launch every wave of the chip asks for its first 6 KB at once, a 25 MB burst.
+    // (Inline asm for the table loads: the compiler would otherwise sink them below the touches and wait for everything.
+    // Older than every load the compiler issues afterwards, they never make its own vmcnt waits too short.)
+    constexpr int TABV = 3;
+    typedef float f512_v4 __attribute__((ext_vector_type(4)));
+    f512_v4 tabv_[TABV];
 #pragma unroll
-            for (int r = 0; r < NSTAGE; ++r) {
-                int64_t idx = e + 4 * (tid & 63) + 256 * r;
-                idx = idx < lim ? idx : lim;
-                warm_ += dsp_load_sample<DTYPE>(wave, idx);
-            }
-        }
+    for (int k = 0; k < TABV; ++k) {
+        const int i = tid * 4 + 64 * WAVES * 4 * k;
+        const float* src = P.tables + (i < P.tab_floats ? i : 0);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(tabv_[k]) : "v"(src) : "memory");
     }
-    for (int i = tid * 4; i < P.tab_floats; i += 64 * WAVES * 4)
-        *reinterpret_cast<float4*>(smem + i) = *reinterpret_cast<const float4*>(P.tables + i);
-    __syncthreads();
-    asm volatile("" :: "v"(warm_));   // the values are not used: this only keeps the warming loads alive
+    if constexpr (!RAGGED) {
+        float warm_[NSTAGE];
+        int G0 = (int)blockIdx.x * WAVES + (tid >> 6);
+        G0 = G0 < (int)P.total_groups ? G0 : (int)P.total_groups - 1;
+        const int u0 = P.flat ? f512_div(8 * G0, P.t_magic, P.t_shift) : f512_div(G0, P.g_magic, P.g_shift);
+        const int t00 = P.flat ? 8 * G0 - u0 * (int)bg.uniform_frames : (G0 - u0 * (int)P.groups_per_utt) * 8;
+        const int64_t e = (int64_t)u0 * bg.uniform_samples + (int64_t)t00 * P.S;
+        const int64_t lim = (int64_t)bg.n_utt * bg.uniform_samples - 4;
+#pragma unroll
+        for (int q = 0; q < NSTAGE; ++q) {
+            int64_t idx = e + 4 * (tid & 63) + 256 * q;
+            idx = idx < lim ? idx : lim;
+            warm_[q] = dsp_load_sample<DTYPE>(wave, idx);
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NSTAGE) : "memory");   // the tables; the NSTAGE touches stay in flight
+#pragma unroll
+        for (int k = 0; k < TABV; ++k) {
+            const int i = tid * 4 + 64 * WAVES * 4 * k;
+            if (i < P.tab_floats) *reinterpret_cast<f512_v4*>(smem + i) = tabv_[k];
+        }
+        for (int i = tid * 4 + 64 * WAVES * 4 * TABV; i < P.tab_floats; i += 64 * WAVES * 4)
+            *reinterpret_cast<float4*>(smem + i) = *reinterpret_cast<const float4*>(P.tables + i);
+        __syncthreads();
+        // not used: this only keeps the touches alive; every wave waits for its OWN first fetch here
+#pragma unroll
+        for (int q = 0; q < NSTAGE; ++q) asm volatile("" :: "v"(warm_[q]));
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < TABV; ++k) {
+            const int i = tid * 4 + 64 * WAVES * 4 * k;
+            if (i < P.tab_floats) *reinterpret_cast<f512_v4*>(smem + i) = tabv_[k];
+        }
+        for (int i = tid * 4 + 64 * WAVES * 4 * TABV; i < P.tab_floats; i += 64 * WAVES * 4)
+            *reinterpret_cast<float4*>(smem + i) = *reinterpret_cast<const float4*>(P.tables + i);
+        __syncthreads();
+    }
     const float* s_win = smem;
     const float4* s_tw1 = reinterpret_cast<const float4*>(smem + P.off_tw1);
     const float* s_dct = smem + P.off_dct;
@@ -328,11 +369,6 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
     const unsigned int stamp_loop0_ = stamp_prev_;
 #endif
 
-#ifdef F512_TOUCH_NEXT
-    float touch_[NSTAGE];   // one dword per 16-byte vector of the NEXT group's samples: pulls them into L2 / the vector cache
-#pragma unroll
-    for (int q = 0; q < NSTAGE; ++q) touch_[q] = 0.f;
-#endif
     for (int r = 0; r <= nfull; ++r) {
         int G;
         if (r < nfull) {
@@ -495,10 +531,6 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
                 }
             }
         }
-#ifdef F512_TOUCH_NEXT
-#pragma unroll
-        for (int q = 0; q < NSTAGE; ++q) asm volatile("" :: "v"(touch_[q]));
-#endif
         F512_FENCE();
         F512_STAMP(1);
 
@@ -672,24 +704,6 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         F512_FENCE();
         F512_STAMP(7);
 
-#ifdef F512_TOUCH_NEXT
-        if constexpr (!RAGGED) {
-            int Gn = -1;
-            if (r + 1 < nfull) Gn = (r + 1) * gstride + (int)blockIdx.x * WAVES + wid;
-            else if (r + 1 == nfull) Gn = nfull * gstride + (int)blockIdx.x + (int)gridDim.x * wid;
-            if (Gn >= 0 && Gn < total_groups) {
-                const F512Group gn = f512_locate<RAGGED>(P, bg, Gn);
-                const int64_t en = gn.s0 + (int64_t)gn.t0 * P.S + 4 * lane;
-                const int64_t lim = (int64_t)bg.n_utt * bg.uniform_samples - 4;
-#pragma unroll
-                for (int q = 0; q < NSTAGE; ++q) {
-                    int64_t idx = en + 256 * q;
-                    idx = idx < lim ? idx : lim;
-                    touch_[q] = dsp_load_sample<DTYPE>(wave, idx);
-                }
-            }
-        }
-#endif
         // ---- sparse mel triangles, log2.  Lane c owns one filter slot per iteration i; its weights sit in one LDS
         //      row, the spectrum bins of a filter are contiguous from a 16-byte aligned start, so both are read as
         //      b128 blocks of 4 taps.  Weights carry 2^21 = 2^32 / 2048; an all-zero filter gives log2(eps 2^32) = -20
@@ -1115,6 +1129,8 @@ static int fast512_launch_t(F512Params P, const void* d_wave, int dtype, const B
     if (bg.uniform_samples > 0) {
         P.groups_per_utt = (bg.uniform_frames + 7) / 8;
         P.total_groups = P.groups_per_utt * bg.n_utt;
+        f512_magic((uint32_t)bg.uniform_frames, P.t_magic, P.t_shift);
+        f512_magic((uint32_t)P.groups_per_utt, P.g_magic, P.g_shift);
         // Flat grouping (groups of 8 cut from the flat frame sequence, a group may span the seam between two
         // utterances) wastes no frame slots at the end of an utterance: 99 frames are 13 groups of 8 otherwise
         // (5 % idle slots).  Needs vector-aligned hops and room for the seam's second segment in the wave buffer.
