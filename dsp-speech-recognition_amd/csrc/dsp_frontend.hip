@@ -491,6 +491,18 @@ int dsp_mfcc_delta_batch(const dsp_plan* plan, const void* d_wave, int wave_dtyp
     int64_t uniform_frames = 0;
     if (uniform_samples > 0) dsp_frame_count(uniform_samples, plan->L, plan->S, &uniform_frames);
     hipStream_t st = (hipStream_t)stream;
+    // Dense batches of the NFFT = 512 plans: ONE kernel writes the finished rows (kernels_fast512.h, "Fused delta").
+    if (uniform_samples > 0 && !g_force_generic && plan->d_fast) {
+        int dev = -1;
+        HIP_TRY(hipGetDevice(&dev));
+        if (dev != plan->device) return fail(DSP_EINVAL, "plan belongs to device %d, current device is %d", plan->device, dev);
+        if (uniform_frames * n_utt != n_frames_total)
+            return fail(DSP_EINVAL, "n_frames_total %lld != n_utt*T (%d*%lld)", (long long)n_frames_total, n_utt, (long long)uniform_frames);
+        const BatchGeom fbg = make_geom(nullptr, nullptr, n_utt, n_frames_total, uniform_samples, plan->L, plan->S);
+        const int frc = fast512_launch_fused(plan, d_wave, wave_dtype, fbg, delta_n, d_out, st);
+        if (frc == DSP_OK) return DSP_OK;
+        if (frc < 0) return fail(frc, "fused MFCC + delta kernel launch failed");
+    }
     // Two passes, every byte written once as part of a full line: the MFCC kernel writes DENSE cepstra
     // [sum T, C] into a pooled scratch buffer, delta_rows_kernel turns them into whole 3C-float rows.
     // (Writing the 52-byte cepstra straight into the 156-byte rows cost 1.5x write amplification and a

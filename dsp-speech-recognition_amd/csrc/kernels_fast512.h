@@ -49,6 +49,8 @@ struct F512Params {
     int64_t groups_per_utt, total_groups;   // uniform batches
     uint32_t t_magic, t_shift;               // x / uniform_frames   = (uint64) x * t_magic >> t_shift   for x < 2^30
     uint32_t g_magic, g_shift;               // x / groups_per_utt, likewise
+    int32_t fd_n;          // fused delta (FD instantiations): delta window N (1 or 2), see "Fused delta" below
+    float fd_inv_den;      // 1 / (2 sum n^2)
     int32_t flat;          // uniform batches: groups are cut from the FLAT frame sequence (a group may span two utterances)
     int32_t seam_off;      // ... then frames of the second utterance sit this many floats further into the LDS image
     const int32_t* group_off;                // ragged: [B+1] prefix of ceil(T_b / 8)
@@ -283,10 +285,55 @@ __device__ __forceinline__ F512Group f512_locate(const F512Params& P, const Batc
     return g;
 }
 
+// Fused delta: the frames a workgroup owns and the run of groups wave `w` takes from them (wave-uniform).
+struct F512Run {
+    int wg_first, wg_end;   // flat frames [wg_first, wg_end) of the workgroup: whole utterances
+    int n_groups;           // groups of this wave (>= 1: the host only launches FD grids whose workgroups hold >= WAVES groups)
+    int first_frame;        // first flat frame of the wave's first group
+};
+__device__ __forceinline__ F512Run f512_run(const BatchGeom& bg, int b, int nb, int w, int waves) {
+    F512Run r;
+    const int T = (int)bg.uniform_frames;
+    const int u0 = (int)((int64_t)b * bg.n_utt / nb), u1 = (int)((int64_t)(b + 1) * bg.n_utt / nb);
+    r.wg_first = u0 * T;
+    r.wg_end = u1 * T;
+    const int ng = (r.wg_end - r.wg_first + 7) >> 3;
+    const int q = ng / waves, rem = ng - q * waves;
+    r.n_groups = q + (w < rem ? 1 : 0);
+    r.first_frame = r.wg_first + 8 * (w * q + (w < rem ? w : rem));
+    return r;
+}
+
+// Fused-delta instantiations cut their groups from a workgroup's own frame range: a group is named by its first
+// (flat) frame, which need not be a multiple of 8.
+__device__ __forceinline__ F512Group f512_locate_frame(const F512Params& P, const BatchGeom& bg, int F0) {
+    F512Group g;
+    g.nsamp = (int)bg.uniform_samples;
+    g.T = (int)bg.uniform_frames;
+    g.utt = f512_div(F0, P.t_magic, P.t_shift);
+    g.t0 = F0 - g.utt * g.T;
+    g.nf1 = g.T - g.t0 < 8 ? g.T - g.t0 : 8;
+    g.s0 = (int64_t)g.utt * bg.uniform_samples;
+    g.row0 = (int64_t)g.utt * bg.uniform_frames;
+    return g;
+}
+
 // RAGGED = false: dense [B, N] batch, N % 4 == 0 (every 16-byte vector is all-valid or all-padding).
 // RAGGED = true : concatenated utterances of any length at any offset; loads stay 16-byte aligned
 //                 (the LDS image starts at the aligned sample below the group's first one).
-template <int NROWS, int NI, int CAPS, int NSTAGE, int DTYPE, int WAVES, bool RAGGED>
+//
+// Fused delta (FD = delta window N = 1 or 2, dense batches only; base.py:70-79 applied twice): the kernel writes whole [x | d | dd] rows.
+//   * Workgroup b owns whole utterances [b U / nb, (b + 1) U / nb), so nothing is needed from another workgroup
+//     (the delta window is edge-replicated at utterance ends); its frames are cut into groups of 8 and wave w takes
+//     a CONTIGUOUS run of them.
+//   * A wave keeps the cepstra of its previous group in two registers.  After group j it writes previous + current
+//     group (16 frames) into its own LDS buffer -- dead at that point -- and emits the rows of the 8 frames in the
+//     middle of that window (delta of the edge-replicated x, then delta of the edge-replicated delta, exactly as the
+//     reference composes them), i.e. rows trail the computation by 2 N <= 4 frames.
+//   * The last 4 rows of a wave's run need the first group of the NEXT wave: every wave publishes its first group's
+//     cepstra in a small LDS area, ONE barrier follows the first iteration, and a final iteration without
+//     computation emits the tail.  The first wave of the workgroup also emits its own first rows.
+template <int NROWS, int NI, int CAPS, int NSTAGE, int DTYPE, int WAVES, bool RAGGED, int FD = 0>
 __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_kernel(F512Params P, BatchGeom bg,
                                                              const void* __restrict__ wave,
                                                              float* __restrict__ out, int64_t ld_out) {
@@ -314,11 +361,18 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
     }
     if constexpr (!RAGGED) {
         float warm_[NSTAGE];
-        int G0 = (int)blockIdx.x * WAVES + (tid >> 6);
-        G0 = G0 < (int)P.total_groups ? G0 : (int)P.total_groups - 1;
-        const int u0 = P.flat ? f512_div(8 * G0, P.t_magic, P.t_shift) : f512_div(G0, P.g_magic, P.g_shift);
-        const int t00 = P.flat ? 8 * G0 - u0 * (int)bg.uniform_frames : (G0 - u0 * (int)P.groups_per_utt) * 8;
-        const int64_t e = (int64_t)u0 * bg.uniform_samples + (int64_t)t00 * P.S;
+        int64_t e;
+        if constexpr (FD) {
+            const F512Run run = f512_run(bg, (int)blockIdx.x, (int)gridDim.x, tid >> 6, WAVES);
+            const int u0 = f512_div(run.first_frame, P.t_magic, P.t_shift);
+            e = (int64_t)u0 * bg.uniform_samples + (int64_t)(run.first_frame - u0 * (int)bg.uniform_frames) * P.S;
+        } else {
+            int G0 = (int)blockIdx.x * WAVES + (tid >> 6);
+            G0 = G0 < (int)P.total_groups ? G0 : (int)P.total_groups - 1;
+            const int u0 = P.flat ? f512_div(8 * G0, P.t_magic, P.t_shift) : f512_div(G0, P.g_magic, P.g_shift);
+            const int t00 = P.flat ? 8 * G0 - u0 * (int)bg.uniform_frames : (G0 - u0 * (int)P.groups_per_utt) * 8;
+            e = (int64_t)u0 * bg.uniform_samples + (int64_t)t00 * P.S;
+        }
         const int64_t lim = (int64_t)bg.n_utt * bg.uniform_samples - 4;
 #pragma unroll
         for (int q = 0; q < NSTAGE; ++q) {
@@ -369,13 +423,23 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
     const unsigned int stamp_loop0_ = stamp_prev_;
 #endif
 
-    for (int r = 0; r <= nfull; ++r) {
-        int G;
-        if (r < nfull) {
-            G = __builtin_amdgcn_readfirstlane(r * gstride + (int)blockIdx.x * WAVES + wid);
-        } else {
-            G = __builtin_amdgcn_readfirstlane(nfull * gstride + (int)blockIdx.x + (int)gridDim.x * wid);
-            if (G >= total_groups) break;
+    // Fused delta: this wave's run of groups, its previous group's cepstra (two per lane) and the halo area behind
+    // the wave buffers where every wave leaves its first group (8 frames x 14 coefficients) for its predecessor.
+    F512Run run = {0, 0, 0, 0};
+    float fd_p0 = 0.f, fd_p1 = 0.f;
+    float* const fd_halo = smem + P.tab_floats + WAVES * F512_WAVE_FLOATS;
+    if constexpr (FD) run = f512_run(bg, (int)blockIdx.x, (int)gridDim.x, wid, WAVES);
+    const int n_iter = FD ? run.n_groups + 1 : nfull + 1;   // FD: one more, computation-free iteration emits the tail rows
+
+    for (int r = 0; r < n_iter; ++r) {
+        int G = 0;
+        if constexpr (!FD) {
+            if (r < nfull) {
+                G = __builtin_amdgcn_readfirstlane(r * gstride + (int)blockIdx.x * WAVES + wid);
+            } else {
+                G = __builtin_amdgcn_readfirstlane(nfull * gstride + (int)blockIdx.x + (int)gridDim.x * wid);
+                if (G >= total_groups) break;
+            }
         }
         // Lane-derived addresses are recomputed every iteration on purpose: hoisted out of the loop
         // they would pin ~30 VGPRs for the whole kernel (the opaque asm stops the hoisting).
@@ -383,8 +447,11 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         int lane = tid & 63;
         asm volatile("" : "+v"(lane));
         const int f = lane >> 3, c = lane & 7;
+        float v0 = 0.f, v1 = 0.f;   // the frame's two cepstral coefficients this lane ends up with
+        do {
+        if constexpr (FD) { if (r >= run.n_groups) break; }
         const int sigma_hi = ((f >> 1) & 1) << 2;  // exchange swizzle: slot ^= (u >> 1) ^ sigma_hi
-        const F512Group grp = f512_locate<RAGGED>(P, bg, G);
+        const F512Group grp = FD ? f512_locate_frame(P, bg, run.first_frame + 8 * r) : f512_locate<RAGGED>(P, bg, G);
         const int utt = grp.utt, t0 = grp.t0, T = grp.T, nsamp = grp.nsamp;
         (void)utt;
         const int base = t0 * P.S;                            // first sample of the group, utterance relative
@@ -775,8 +842,8 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         for (int r = 0; r < 8; ++r) h8[r] = cep[r] + dpp_f32<0x141>(cep[8 + r]);   // partner c ^ 7
 #pragma unroll
         for (int r = 0; r < 4; ++r) h4[r] = h8[r] + dpp_f32<0x4E>(h8[4 + r]);      // partner c ^ 2
-        float v0 = h4[0] + dpp_f32<0xB1>(h4[2]);                                   // partner c ^ 1
-        float v1 = h4[1] + dpp_f32<0xB1>(h4[3]);
+        v0 = h4[0] + dpp_f32<0xB1>(h4[2]);                                         // partner c ^ 1
+        v1 = h4[1] + dpp_f32<0xB1>(h4[3]);
         {
             const float2 bias = *reinterpret_cast<const float2*>(smem + P.off_bias + 2 * c);   // removes the 2^32
             v0 += bias.x;
@@ -789,21 +856,142 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         }
 
         F512_STAMP(9);
-        // ---- store: lane c writes its two adjacent coefficients ----
-        const int cb = ((c & 1) << 1) ^ ((c & 2) << 1) ^ ((c & 4) ? 14 : 0);
-        const int t = t0 + f;
-        // flat grouping: rows of the next utterance follow directly, valid while inside the batch
-        const bool row_ok = (!RAGGED && P.flat) ? (grp.row0 + t < bg.total_frames) : (t < T);
-        if (row_ok) {
-            float* o = out + (grp.row0 + t) * ld_out + cb;
-            if (cb + 1 < P.C) {
-                f512_f2u v;
-                v.x = v0;
-                v.y = v1;
-                *reinterpret_cast<f512_f2u*>(o) = v;
-            } else if (cb < P.C) {
-                o[0] = v0;
+        if constexpr (!FD) {
+            // ---- store: lane c writes its two adjacent coefficients ----
+            const int cb = ((c & 1) << 1) ^ ((c & 2) << 1) ^ ((c & 4) ? 14 : 0);
+            const int t = t0 + f;
+            // flat grouping: rows of the next utterance follow directly, valid while inside the batch
+            const bool row_ok = (!RAGGED && P.flat) ? (grp.row0 + t < bg.total_frames) : (t < T);
+            if (row_ok) {
+                float* o = out + (grp.row0 + t) * ld_out + cb;
+                if (cb + 1 < P.C) {
+                    f512_f2u v;
+                    v.x = v0;
+                    v.y = v1;
+                    *reinterpret_cast<f512_f2u*>(o) = v;
+                } else if (cb < P.C) {
+                    o[0] = v0;
+                }
             }
+        }
+        } while (0);
+        if constexpr (FD) {
+            // ---- fused delta: window rows 0..7 = previous group, 8..15 = this group (or, in the final iteration,
+            //      the next wave's first group from the halo area); rows 4..11 are emitted ----
+            const int pr = (((c & 1) << 1) ^ ((c & 2) << 1) ^ ((c & 4) ? 14 : 0)) >> 1;   // coefficient pair of this lane; 7 = none
+            const bool tail = r >= run.n_groups;
+            if (r == 0) {   // leave the first group for the wave before this one; the workgroup's only barrier
+                if (pr < 7) *reinterpret_cast<float2*>(fd_halo + (wid * 8 + f) * 14 + 2 * pr) = make_float2(v0, v1);
+                __syncthreads();
+            }
+            if (tail) {
+                const int nw = wid + 1 < WAVES ? wid + 1 : wid;   // no next wave: rows 8.. lie outside the workgroup, never used
+                const float2 hv = *reinterpret_cast<const float2*>(fd_halo + (nw * 8 + f) * 14 + 2 * (pr < 7 ? pr : 0));
+                v0 = hv.x;
+                v1 = hv.y;
+            }
+            const bool emit = r > 0 || run.first_frame == run.wg_first;   // first iteration: only the workgroup's first wave has rows due
+            if (emit) {
+                float* const tx = wbuf;          // [16][16] cepstra of the window
+                float* const td = wbuf + 256;    // [16][16] their deltas (rows 2..13)
+                *reinterpret_cast<float2*>(tx + f * 16 + 2 * pr) = make_float2(fd_p0, fd_p1);
+                *reinterpret_cast<float2*>(tx + (8 + f) * 16 + 2 * pr) = make_float2(v0, v1);
+                const int Fw = run.first_frame + 8 * (r - 1);                 // flat frame of window row 0 (>= -8)
+                // row of the window where an utterance starts (16 or more: none): edge replication stops there
+                const int Tn = (int)bg.uniform_frames;
+                const int tstart = (Fw + Tn) - f512_div(Fw + Tn, P.t_magic, P.t_shift) * Tn;   // (Fw mod T), Fw >= -8 > -T
+                const int sb = tstart == 0 ? 0 : Tn - tstart;
+                constexpr int N = FD;
+                const float inv_den = P.fd_inv_den;
+                const int C = P.C;
+                const int Fi = Fw + 4 + f;                                    // the row this lane's frame slot emits
+                float* const o = out + (int64_t)Fi * (3 * C) + 2 * pr;
+                float2 ox, od, odd;
+                bool row_ok;
+                F512_FENCE();
+                if ((sb == 0 || sb >= 16) && Fw + 4 >= run.wg_first && Fw + 12 <= run.wg_end) {
+                    // No utterance boundary inside the window (23 of 25 windows of a 2 x 99-frame workgroup): nothing to
+                    // clamp, rows at immediate offsets, and ONE LDS round trip -- the lane reads rows i - 2N .. i + 2N
+                    // and forms the deltas of rows i - N .. i + N itself (same operations, same order as below).
+                    const float* b = tx + f * 16 + 2 * pr;                    // window row (4 + f) - 4
+                    float2 xr[4 * N + 1];
+#pragma unroll
+                    for (int k = 0; k <= 4 * N; ++k) xr[k] = *reinterpret_cast<const float2*>(b + (4 - 2 * N + k) * 16);
+                    float2 dl[2 * N + 1];
+#pragma unroll
+                    for (int k = 0; k <= 2 * N; ++k) {                        // delta of row i - N + k: centre xr[N + k]
+                        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                        for (int n = 1; n <= N; ++n) {
+                            a0 = fmaf((float)n, xr[N + k + n].x - xr[N + k - n].x, a0);
+                            a1 = fmaf((float)n, xr[N + k + n].y - xr[N + k - n].y, a1);
+                        }
+                        dl[k] = make_float2(a0 * inv_den, a1 * inv_den);
+                        // rounded here, as when the value goes through memory: keeps -ffp-contract from folding the product
+                        // into the subtraction below, so the rows equal the two-kernel path bit for bit
+                        asm volatile("" : "+v"(dl[k].x), "+v"(dl[k].y));
+                    }
+                    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                    for (int n = 1; n <= N; ++n) {
+                        a0 = fmaf((float)n, dl[N + n].x - dl[N - n].x, a0);
+                        a1 = fmaf((float)n, dl[N + n].y - dl[N - n].y, a1);
+                    }
+                    ox = xr[2 * N];
+                    od = dl[N];
+                    odd = make_float2(a0 * inv_den, a1 * inv_den);
+                    row_ok = true;
+                } else {
+#pragma unroll
+                    for (int pass = 0; pass < 2; ++pass) {   // delta of rows 2..9, then 10..13 (rows above 13 repeat row 13)
+                        const int i = pass == 0 ? 2 + f : (10 + f < 13 ? 10 + f : 13);
+                        const int lo = i >= sb ? sb : 0, hi = i < sb ? sb - 1 : 15;
+                        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                        for (int n = 1; n <= N; ++n) {
+                            const int ip = i + n < hi ? i + n : hi, im = i - n > lo ? i - n : lo;
+                            const float2 xp = *reinterpret_cast<const float2*>(tx + ip * 16 + 2 * pr);
+                            const float2 xm = *reinterpret_cast<const float2*>(tx + im * 16 + 2 * pr);
+                            a0 = fmaf((float)n, xp.x - xm.x, a0);
+                            a1 = fmaf((float)n, xp.y - xm.y, a1);
+                        }
+                        *reinterpret_cast<float2*>(td + i * 16 + 2 * pr) = make_float2(a0 * inv_den, a1 * inv_den);
+                    }
+                    F512_FENCE();
+                    const int i = 4 + f;
+                    const int lo = i >= sb ? sb : 0, hi = i < sb ? sb - 1 : 15;
+                    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                    for (int n = 1; n <= N; ++n) {
+                        const int ip = i + n < hi ? i + n : hi, im = i - n > lo ? i - n : lo;
+                        const float2 dp = *reinterpret_cast<const float2*>(td + ip * 16 + 2 * pr);
+                        const float2 dm = *reinterpret_cast<const float2*>(td + im * 16 + 2 * pr);
+                        a0 = fmaf((float)n, dp.x - dm.x, a0);
+                        a1 = fmaf((float)n, dp.y - dm.y, a1);
+                    }
+                    ox = *reinterpret_cast<const float2*>(tx + i * 16 + 2 * pr);
+                    od = *reinterpret_cast<const float2*>(td + i * 16 + 2 * pr);
+                    odd = make_float2(a0 * inv_den, a1 * inv_den);
+                    row_ok = Fi >= run.wg_first && Fi < run.wg_end;
+                }
+                if (row_ok) {
+                    if (2 * pr + 1 < C) {
+                        f512_f2u v;
+                        v.x = ox.x; v.y = ox.y;
+                        *reinterpret_cast<f512_f2u*>(o) = v;
+                        v.x = od.x; v.y = od.y;
+                        *reinterpret_cast<f512_f2u*>(o + C) = v;
+                        v.x = odd.x; v.y = odd.y;
+                        *reinterpret_cast<f512_f2u*>(o + 2 * C) = v;
+                    } else if (2 * pr < C) {
+                        o[0] = ox.x;
+                        o[C] = od.x;
+                        o[2 * C] = odd.x;
+                    }
+                }
+            }
+            fd_p0 = v0;
+            fd_p1 = v1;
         }
         F512_FENCE();
         F512_STAMP(10);
@@ -1183,4 +1371,64 @@ static inline int fast512_launch(const dsp_plan* p, const void* d_wave, int dtyp
     if (fp->variant == 1 && fp->caps == 1) return fast512_launch_t<25, 5, 1, 6>(fp->P, d_wave, dtype, bg, d_out, ld_out, st, pre);
     if (fp->variant == 1) return fast512_launch_t<25, 5, 0, 6>(fp->P, d_wave, dtype, bg, d_out, ld_out, st, pre);
     return fast512_launch_t<32, F512_MAX_NI, 0, 9>(fp->P, d_wave, dtype, bg, d_out, ld_out, st, pre);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused MFCC + delta + delta-delta (FD instantiations): one launch writes the whole [sum T, 3 C] rows
+// ------------------------------------------------------------------------------------------------
+#define F512_FD_HALO_FLOATS (F512_WAVES * 8 * 14)
+
+template <int NROWS, int NI, int CAPS, int NSTAGE>
+static int fast512_launch_fused_t(F512Params P, const void* d_wave, int dtype, const BatchGeom& bg, int delta_n,
+                                  float* d_out, hipStream_t st) {
+    const int64_t T = bg.uniform_frames;
+    const int64_t blocks = (int64_t)dsp_cu_count() * (16 / F512_WAVES);
+    // every workgroup owns whole utterances and at least F512_WAVES groups of 8 frames; a window of 16 frames meets at
+    // most one utterance boundary; the delta window reaches 2 N <= 4 frames back
+    if (delta_n < 1 || delta_n > 2 || P.C > 14 || T < 8 * F512_WAVES - 7 || bg.n_utt < blocks) return 1;
+    if ((P.S % 4) != 0 || P.L <= P.S || 16 * NROWS <= P.S) return 1;
+    const int seam = (16 * NROWS - P.S + 3) / 4 * 4;
+    if (7 * P.S + 16 * NROWS + seam + 4 > F512_WAVE_FLOATS || 7 * P.S + 16 * NROWS + seam > 256 * (NSTAGE + 1)) return 1;
+    if (bg.total_frames + T + 16 > 0x3fffffff) return 1;
+    P.flat = 1;
+    P.seam_off = seam;
+    P.groups_per_utt = (T + 7) / 8;
+    P.total_groups = (bg.total_frames + 7) / 8;
+    f512_magic((uint32_t)T, P.t_magic, P.t_shift);
+    f512_magic((uint32_t)P.groups_per_utt, P.g_magic, P.g_shift);
+    P.fd_n = delta_n;
+    int den = 0;
+    for (int i = 1; i <= delta_n; ++i) den += i * i;
+    P.fd_inv_den = (float)(1.0 / (2.0 * den));
+    const size_t lds = ((size_t)P.tab_floats + (size_t)F512_WAVES * F512_WAVE_FLOATS + F512_FD_HALO_FLOATS) * sizeof(float);
+    if (lds > 80 * 1024) return 1;   // two workgroups per CU
+    const int64_t ld = 3 * (int64_t)P.C;
+    const int nblk = (int)blocks;
+#define F512_FD_LAUNCH(DT, FDN)                                                                          \
+    do {                                                                                                 \
+        auto k = mfcc512_kernel<NROWS, NI, CAPS, NSTAGE, DT, F512_WAVES, false, FDN>;                    \
+        static size_t granted[DSP_MAX_DEVICES] = {};                                                     \
+        if (dsp_ensure_dynamic_lds((const void*)k, lds, granted) != 0) return DSP_EHIP;                  \
+        k<<<nblk, 64 * F512_WAVES, lds, st>>>(P, bg, d_wave, d_out, ld);                                 \
+    } while (0)
+    if (dtype == DSP_WAVE_I16) {
+        if (delta_n == 1) F512_FD_LAUNCH(DSP_WAVE_I16, 1); else F512_FD_LAUNCH(DSP_WAVE_I16, 2);
+    } else {
+        if (delta_n == 1) F512_FD_LAUNCH(DSP_WAVE_F32, 1); else F512_FD_LAUNCH(DSP_WAVE_F32, 2);
+    }
+#undef F512_FD_LAUNCH
+    return hipGetLastError() == hipSuccess ? DSP_OK : DSP_EHIP;
+}
+
+// DSP_OK: launched; 1: this batch is not one the fused form serves (the caller takes the two-kernel path); < 0: HIP error.
+static inline int fast512_launch_fused(const dsp_plan* p, const void* d_wave, int dtype, const BatchGeom& bg, int delta_n,
+                                       float* d_out, hipStream_t st) {
+    static const bool off = getenv("DSP_F512_NOFUSE") != nullptr;   // A/B switch
+    if (off || !fast512_applicable(p, bg, d_wave, dtype) || bg.uniform_samples <= 0) return 1;
+    const Fast512Plan* fp = static_cast<const Fast512Plan*>(p->d_fast);
+    if (fp->variant == 0 && fp->caps == 2) return fast512_launch_fused_t<25, 4, 2, 6>(fp->P, d_wave, dtype, bg, delta_n, d_out, st);
+    if (fp->variant == 0) return fast512_launch_fused_t<25, 4, 0, 6>(fp->P, d_wave, dtype, bg, delta_n, d_out, st);
+    if (fp->variant == 1 && fp->caps == 1) return fast512_launch_fused_t<25, 5, 1, 6>(fp->P, d_wave, dtype, bg, delta_n, d_out, st);
+    if (fp->variant == 1) return fast512_launch_fused_t<25, 5, 0, 6>(fp->P, d_wave, dtype, bg, delta_n, d_out, st);
+    return fast512_launch_fused_t<32, F512_MAX_NI, 0, 9>(fp->P, d_wave, dtype, bg, delta_n, d_out, st);
 }

@@ -121,6 +121,42 @@ def test_ragged_calls_queued_back_to_back(plan):
             assert np.array_equal(got, jobs[j][2]), (rep, j)
 
 
+@pytest.mark.parametrize('B,N,delta_n,dtype', [
+    (1024, 16000, 2, np.float32),     # configs[1]: 2 utterances per workgroup, 99 frames each (groups span the seam)
+    (515, 16000, 2, np.int16),        # uneven split: workgroups of 1 and 2 utterances
+    (700, 16880, 1, np.float32),      # T = 104 (a multiple of 8), delta window 1
+    (1300, 9600, 2, np.float32),      # T = 59: short utterances, 2-3 per workgroup
+])
+def test_fused_delta_kernel_equals_the_two_kernel_path(plan, B, N, delta_n, dtype):
+    """Dense batches of >= 2 x CUs utterances take the fused MFCC + delta + delta-delta kernel
+    (kernels_fast512.h, "Fused delta": workgroups own whole utterances, rows trail the computation by 2 N frames,
+    one barrier).  Its rows must equal, bit for bit, what the MFCC kernel followed by dsp_delta_batch gives
+    (same cepstra arithmetic, same delta formula, base.py:70-79 twice), and match the oracle on sampled utterances."""
+    import torch
+    from features import _native as nat
+    lib = nat.load()
+    waves = _batch(91, B, N, dtype=dtype)
+    lay = plan.layout(waves)
+    T = lay.total_frames // B
+    dev = torch.device('cuda', 0)
+    d_wave = torch.from_numpy(waves).to(dev)
+    wd = nat.WAVE_I16 if dtype == np.int16 else nat.WAVE_F32
+    fused = torch.full((B * T, 39), float('nan'), device=dev)
+    plan.run_raw(d_wave.data_ptr(), wd, lay, fused.data_ptr(), delta_n, None)
+    two = torch.full((B * T, 39), float('nan'), device=dev)
+    nat.check(lib.dsp_features_batch(plan.plan.handle, d_wave.data_ptr(), wd, None, None, B, B * T, N, nat.OUT_MFCC,
+                                     two.data_ptr(), 39, None, None))
+    nat.check(lib.dsp_delta_batch(two.data_ptr(), 39, None, B, B * T, T, 13, delta_n, two.data_ptr() + 13 * 4, 39,
+                                  two.data_ptr() + 26 * 4, 39, None))
+    torch.cuda.synchronize()
+    fused, two = fused.cpu().numpy(), two.cpu().numpy()
+    assert np.isfinite(fused).all()
+    assert np.array_equal(fused, two), np.argwhere(fused != two)[:8]
+    for b in (0, 1, B // 2, B - 2, B - 1):
+        ref = dsp_oracle.mfcc_delta(waves[b].astype(np.float64), delta_n=delta_n, winfunc=np.hamming, **CFG)
+        assert normwise(fused[b * T:(b + 1) * T], ref) <= TOL, b
+
+
 def test_workspace_pool_stays_bounded_when_the_host_queues_ahead(plan):
     """dsp_mfcc_delta_batch leases its dense-cepstra scratch from the workspace pool.  A host
     that queues hundreds of steps without synchronising must not grow the pool with the queue depth: work on ONE
