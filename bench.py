@@ -3,7 +3,7 @@
 (BASELINE.json `metric`), on BASELINE.json configs[1]:
 
     one step = one pass of the hot path over a batch of 1024 synthetic 1 s utterances
-               -> [1024*99, 39] = MFCC | delta | delta-delta   (dsp_mfcc_delta_batch, C ABI)
+               -> [1024*99, 39] = MFCC | delta | delta-delta   (dsp_mfcc_delta_batch, C ABI: ONE fused kernel)
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -11,8 +11,8 @@
 Inputs are resident in HBM before the timed region; successive steps rotate over distinct input
 batches whose total size exceeds the 256 MiB Infinity Cache, so reads come from HBM.  Utterances
 shard across ranks with no data-path collective (weak scaling: every rank owns its own batches);
-the RCCL all-gather of one step's features (configs[2]) is timed separately and reported under
-"gather" -- it is not part of `value`.
+configs[2] (12 500 utterances per GPU in one launch, then the RCCL gather of the [12500*99, 39] result to rank 0)
+is timed separately and reported under "gather" -- it is not part of `value`.
 
 rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
 """
@@ -39,23 +39,36 @@ BYTES_PER_FRAME_ALL = 4.0 * N / T + 4.0 * 39         # 802.5: SURVEY 8d, MFCC+de
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-# Second roof (fp32 vector issue): wave instructions the fused MFCC kernel executes per frame x 64 lanes,
-# from the rocprofv3 SQ_INSTS_VALU pass in profiles/ (DESIGN.md section 7), against 256 CUs x 4 SIMDs x
-# 32 lanes x 2.4 GHz = 78.6 T lane-ops/s.
-VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9
+# Second roof (fp32 vector issue): wave instructions the step's kernel executes per frame x 64 lanes, from the
+# rocprofv3 SQ_INSTS_VALU pass in profiles/ (DESIGN.md section 7), against 256 CUs x 4 SIMDs x 32 lanes x clock --
+# at the nominal 2.4 GHz and at the shader clock the chip actually holds under this kernel (stamped in-kernel,
+# same profiles file).
+VALU_LANES = 256 * 4 * 32
+NOMINAL_GHZ = 2.4
 
 
 def compute_roof(kernel_ms):
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r2_instr.json')) as fh:
-            ij = json.load(fh)
-        lane_ops = float(ij['valu_lane_ops_per_frame'])
-        src = 'profiles/r2_instr.json'
-    except (OSError, ValueError, KeyError):
-        lane_ops, src = 1735.0 * 64 / 8, 'profiles/r1_pmc_summary.txt (1735 VALU wave-instructions per 8 frames)'
+    lane_ops, clock, src = None, None, None
+    for name in ('r3_instr.json', 'r2_instr.json'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', name)) as fh:
+                ij = json.load(fh)
+            lane_ops = float(ij['valu_lane_ops_per_frame'])
+            clock = float(ij.get('shader_clock_ghz_under_load', 0)) or None
+            src = f'profiles/{name}'
+            break
+        except (OSError, ValueError, KeyError):
+            continue
+    if lane_ops is None:
+        return None
     ach = lane_ops * B * T / (kernel_ms * 1e-3)
-    return {'bound': 'valu', 'achieved': ach / 1e12, 'peak': VALU_PEAK_LANEOPS / 1e12, 'unit': 'T lane-ops/s',
-            'frac': ach / VALU_PEAK_LANEOPS, 'lane_ops_per_frame': lane_ops, 'source': src}
+    out = {'bound': 'valu', 'achieved': ach / 1e12, 'peak': VALU_LANES * NOMINAL_GHZ * 1e9 / 1e12, 'unit': 'T lane-ops/s',
+           'frac': ach / (VALU_LANES * NOMINAL_GHZ * 1e9), 'clock_ghz_nominal': NOMINAL_GHZ,
+           'lane_ops_per_frame': lane_ops, 'source': src}
+    if clock:
+        out.update({'clock_ghz_measured': clock, 'peak_at_measured_clock': VALU_LANES * clock * 1e9 / 1e12,
+                    'frac_at_measured_clock': ach / (VALU_LANES * clock * 1e9)})
+    return out
 
 
 def synth_batch(seed):
@@ -105,6 +118,90 @@ def cpu_baseline(budget_s=8.0):
                   f'workload, NumPy oracle mfcc+delta+delta2, {busy:.1f} s of CPU work per process',
         'single_core_value': single,
     }
+
+
+SHARE_UTT = 12500     # configs[2]: 100 000 utterances over 8 GPUs
+
+
+def share_launch(dev, plan, reps=20):
+    """configs[2]'s per-GPU share: 12 500 x 1 s utterances (800 MB of fp32, generated on the device) through ONE
+    launch of the step's kernel -> [12500*99, 39], HIP-event timed.  Returns (result tensor, dict)."""
+    import torch
+    from features import _native as nat
+    g = torch.Generator(device=dev).manual_seed(12)
+    w = torch.empty((SHARE_UTT, N), dtype=torch.float32, device=dev)
+    for i in range(0, SHARE_UTT, 2500):                      # in slices: randn's temporaries stay small
+        w[i:i + 2500] = 0.25 * torch.randn((2500, N), device=dev, generator=g)
+    lay = plan.layout(np.empty((SHARE_UTT, N), dtype=np.float32))
+    out = torch.empty((SHARE_UTT * T, plan.width(DELTA_N)), dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream(dev)
+    for _ in range(10):      # ~5 ms of work first: the clock ramps after the host-side pauses before this point
+        plan.run_raw(w.data_ptr(), nat.WAVE_F32, lay, out.data_ptr(), DELTA_N, st.cuda_stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    e0.record(st)
+    for _ in range(reps):
+        plan.run_raw(w.data_ptr(), nat.WAVE_F32, lay, out.data_ptr(), DELTA_N, st.cuda_stream)
+    e1.record(st)
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / reps
+    del w
+    frames = SHARE_UTT * T
+    return out, {'workload': f'configs[2] share of one GPU: {SHARE_UTT} x 1 s utterances in ONE launch -> [{frames}, 39]',
+                 'frames': frames, 'ms_per_launch': ms, 'frames_per_s': frames / ms * 1e3,
+                 'algorithmic_GBps': BYTES_PER_FRAME_ALL * frames / ms / 1e6,
+                 'frac_of_hbm_peak': BYTES_PER_FRAME_ALL * frames / ms / 1e6 / HBM_PEAK_GBPS}
+
+
+def model_path(dev, batch=512):
+    """configs[4]: the reference's classifier input (model.py:113-135, test path) from device-resident 44.1 kHz int16
+    clips -- VAD, endpoint rule, trim, unit variance, NFFT=1536 MFCC, mean removal, delta(3) x 2, z-score,
+    [200, B, 39] -- followed by the forward pass of the reference's vanilla RNN classifier (features/classifier.py,
+    pinned to the reference class by tests/test_classifier_golden.py; random weights: the reference ships none, so
+    accuracy is not measured)."""
+    import torch
+    from features.model_glue import ModelFeatureBatch
+    from features.classifier import RNNHead, fill_parameters
+    rate = 44100
+    rng = np.random.default_rng(9)
+    clips = []
+    for _ in range(batch):
+        n = int(rng.uniform(1.0, 2.0) * rate)
+        x = rng.normal(0, 30, n)
+        blen = int(rng.uniform(0.5, 0.9) * n)
+        b0 = int(rng.integers(0, n - blen))
+        t = np.arange(blen) / rate
+        x[b0:b0 + blen] += 8000 * np.sin(2 * np.pi * rng.uniform(100, 300) * t) * np.hanning(blen)
+        clips.append(np.clip(np.round(x), -32768, 32767).astype(np.int16))
+    so = np.concatenate([[0], np.cumsum([len(c) for c in clips])]).astype(np.int64)
+    src = torch.from_numpy(np.concatenate(clips)).to(dev)
+    mfb = ModelFeatureBatch(rate=rate)
+    lay = mfb.pipe.prepare(so, delta_n=0)
+    head = RNNHead().to(dev).eval()
+    fill_parameters(head, 1)
+    for _ in range(2):
+        inp, len0, _ = mfb.run(src, layout=lay)
+        with torch.no_grad():
+            logits = head(inp, len0)
+    torch.cuda.synchronize(dev)
+    reps, t_fe, t_clf = 5, 0.0, 0.0
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        inp, len0, _ = mfb.run(src, layout=lay)               # ends with a host synchronisation (downloads the lengths)
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            logits = head(inp, len0)
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        t_fe += t1 - t0
+        t_clf += t2 - t1
+    t_fe, t_clf = t_fe / reps, t_clf / reps
+    return {'workload': f'configs[4]: {batch} int16 clips of 1-2 s at 44.1 kHz ({int(so[-1])} samples) resident on the '
+                        f'device -> model.py feature pipeline -> [200, {batch}, 39] -> 3-layer bidirectional GRU(200) '
+                        f'classifier forward (random weights)',
+            'front_end_ms': t_fe * 1e3, 'classifier_ms': t_clf * 1e3, 'utterances_per_s': batch / (t_fe + t_clf),
+            'front_end_utterances_per_s': batch / t_fe, 'logits_shape': list(logits.shape),
+            'accuracy': 'unpinned: the reference ships neither data nor weights'}
 
 
 def other_paths(dev):
@@ -170,6 +267,11 @@ def other_paths(dev):
                     f'-> trim + unit variance -> ragged MFCC+delta+delta2, no host round trip',
         'end_to_end_us': us, 'mfcc_frames': frames, 'utterances_per_s': B / (us * 1e-6),
         'input_GBps': 2.0 * int(so[-1]) / us / 1e3}
+    del d_wave, d_feat, w2, o2
+    out['configs4_model'] = model_path(dev)
+    plan = FeaturePlan(winfunc=np.hamming, **CFG)
+    share_out, out['configs2_share'] = share_launch(dev, plan)
+    del share_out
     return out
 
 
@@ -204,8 +306,27 @@ def launch_ranks(args):
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rcs = [p.wait() for p in procs]
-    raise SystemExit(max(abs(rc) for rc in rcs))
+    # poll: a rank that dies at start-up would leave the others blocked in their first barrier for ever
+    deadline = time.time() + float(os.environ.get('BENCH_RANKS_TIMEOUT_S', '1500'))
+    rcs = [None] * len(procs)
+    while any(rc is None for rc in rcs):
+        for i, pr in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = pr.poll()
+        failed = [rc for rc in rcs if rc not in (None, 0)]
+        if failed or time.time() > deadline:
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.terminate()
+            for pr in procs:
+                try:
+                    pr.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    pr.kill()
+            sys.stderr.write('bench.py: a rank failed or the run timed out; the other ranks were stopped\n')
+            raise SystemExit(max([abs(rc) for rc in failed] + [1]))
+        time.sleep(0.05)
+    raise SystemExit(0)
 
 
 def main():
@@ -336,30 +457,37 @@ def main():
     spans = np.array([b[1] for b in blocks])
     dt = float(np.median(walls))
 
-    # --- dominant kernel (fused MFCC) timed alone with events on the launch stream, same rotation ---
+    # --- dominant kernel: the step's ONE kernel (fused MFCC + delta + delta-delta, dsp_mfcc_delta_batch) timed alone,
+    #     launches back to back on ONE stream, HIP events on that stream, same input rotation; and, for the record,
+    #     the MFCC-only kernel of dsp_features_batch (what rounds 1-2 reported) ---
     lib = nat.load()
-
     cep = [torch.empty((B * T, plan.C), dtype=torch.float32, device=dev) for _ in range(2)]
 
-    def mfcc_only(i):   # dense [B*T, 13] cepstra: exactly the launch dsp_mfcc_delta_batch makes for a step
+    def step_one_stream(i):
+        plan.run_raw(waves[i % len(waves)].data_ptr(), nat.WAVE_F32, layout, outs[0][i & 1].data_ptr(), DELTA_N, sp)
+
+    def mfcc_only(i):
         nat.check(lib.dsp_features_batch(plan.plan.handle, waves[i % len(waves)].data_ptr(), nat.WAVE_F32, None,
                                          None, B, B * T, N, nat.OUT_MFCC, cep[i & 1].data_ptr(), plan.C,
                                          None, sp))
 
-    ksteps = 200
-    kev0, kev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ktimes = []
-    for rep in range(5):
-        for i in range(5):
-            mfcc_only(i)
-        torch.cuda.synchronize(dev)
-        kev0.record(stream)
-        for i in range(ksteps):
-            mfcc_only(i)
-        kev1.record(stream)
-        torch.cuda.synchronize(dev)
-        ktimes.append(kev0.elapsed_time(kev1) / ksteps)
-    kernel_ms = float(np.median(ktimes))
+    def event_timed(fn, ksteps=200):
+        kev0, kev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ktimes = []
+        for rep in range(5):
+            for i in range(5):
+                fn(i)
+            torch.cuda.synchronize(dev)
+            kev0.record(stream)
+            for i in range(ksteps):
+                fn(i)
+            kev1.record(stream)
+            torch.cuda.synchronize(dev)
+            ktimes.append(kev0.elapsed_time(kev1) / ksteps)
+        return float(np.median(ktimes))
+
+    kernel_ms = event_timed(step_one_stream)
+    mfcc_only_ms = event_timed(mfcc_only)
 
     # --- parity guard on batch 0 (outside the timed region): HIP path vs the CPU oracle ---
     parity = None
@@ -373,21 +501,27 @@ def main():
             ref = dsp_oracle.mfcc_delta(host0[b].astype(np.float64), delta_n=DELTA_N, winfunc=np.hamming, **CFG)
             parity = max(parity, float(np.max(np.abs(got[b] - ref)) / np.max(np.abs(ref))))
 
-    # --- configs[2]: RCCL all-gather of one step's features, timed on its own ---
+    # --- configs[2]: every rank runs its 12 500-utterance share in ONE launch, then the [12500*99, 39] results are
+    #     gathered to rank 0 over RCCL (features/distributed.py: grouped send/recv, other ranks receive nothing).
+    #     Timed on its own, never part of `value`. ---
     gather = None
     if world > 1 and not args.no_gather and not REHEARSE:
-        gbuf = torch.empty((world * B * T, D), dtype=torch.float32, device=dev)
-        for _ in range(2):
-            dist.all_gather_into_tensor(gbuf, outs[0][0])
+        from features.distributed import gather_features
+        share_out, share = share_launch(dev, plan, reps=10)
+        rows, _ = gather_features(share_out, dst=0)          # warm-up (communicator set-up, allocations)
+        del rows
         sync_all()
         g0 = time.perf_counter()
-        reps = 5
-        for _ in range(reps):
-            dist.all_gather_into_tensor(gbuf, outs[0][0])
+        rows, counts = gather_features(share_out, dst=0)
         sync_all()
-        gms = max_over_ranks((time.perf_counter() - g0) / reps * 1e3)
-        gather = {'collective': 'rccl all_gather_into_tensor', 'bytes_per_rank': B * T * D * 4, 'ms': gms,
-                  'algbw_GBps': world * B * T * D * 4 / gms / 1e6}
+        gms = max_over_ranks((time.perf_counter() - g0) * 1e3)
+        nbytes = SHARE_UTT * T * D * 4
+        gather = {'collective': 'rccl gather to rank 0 (grouped send/recv, features/distributed.py::gather_features(dst=0))',
+                  'bytes_per_rank': nbytes, 'ms': gms, 'root_ingest_GBps': (world - 1) * nbytes / gms / 1e6,
+                  'share_launch_ms': max_over_ranks(share['ms_per_launch']),
+                  'share_frames_per_s_all_ranks': world * SHARE_UTT * T / max_over_ranks(share['ms_per_launch']) * 1e3,
+                  'rows_at_root': None if rows is None else int(rows.shape[0])}
+        del rows, share_out
     per_rank_ms = None
     if world > 1:
         mine = torch.tensor([float(np.median([b[1] for b in blocks])) / args.steps], dtype=torch.float64, device=cdev)
@@ -397,7 +531,7 @@ def main():
 
     # HBM traffic per launch measured with rocprofv3 PMC passes (cannot be collected inside this process)
     traffic, step_traffic, traffic_source = None, None, None
-    for name in ('r2_traffic.json', 'r1_traffic.json'):
+    for name in ('r3_traffic.json',):     # FETCH / WRITE passes of THIS kernel (the fused one); older files describe the round-2 kernel
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as fh:
                 tj = json.load(fh)
@@ -413,7 +547,7 @@ def main():
 
     frames_total = float(world) * B * T * args.steps
     value = frames_total / dt
-    achieved = BYTES_PER_FRAME_MFCC * B * T / (kernel_ms * 1e-3) / 1e9
+    achieved = BYTES_PER_FRAME_ALL * B * T / (kernel_ms * 1e-3) / 1e9
     res = {
         'metric': 'MFCC frames/sec at 16 kHz, 25 ms/10 ms, nfft=512, 40 mel, 13 cep',
         'value': value, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -434,14 +568,20 @@ def main():
                      'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic, 'traffic_source': traffic_source,
                      'step_traffic': step_traffic,
                      'frac_of_measured_copy_ceiling': achieved / 6290.0,   # MI355X_MICROARCH.md: 6.29 TB/s copy
-                     'algorithmic_bytes_per_launch': BYTES_PER_FRAME_MFCC * B * T,
-                     'kernel': 'fused MFCC kernel (dsp_features_batch, DSP_OUT_MFCC)',
+                     'algorithmic_bytes_per_launch': BYTES_PER_FRAME_ALL * B * T,
+                     'kernel': 'fused MFCC + delta + delta-delta kernel (dsp_mfcc_delta_batch: the whole step is this one '
+                               'launch; reads 4 B x 16000 per utterance, writes 156 B per frame)',
                      'kernel_ms': kernel_ms, 'kernel_ms_note': 'one launch stream, back to back, HIP events',
                      'kernel_ms_overlapped': float(np.median(spans)) / args.steps,
                      'kernel_ms_overlapped_note': 'device-side span of a timed block (HIP events on every launch '
-                                                  'stream, max over streams) / K: MFCC + delta kernels of one step '
-                                                  'under the stream overlap of the timed region; <= ms_per_step',
-                     'bytes_per_frame': BYTES_PER_FRAME_MFCC, 'frames_per_launch': B * T,
+                                                  'stream, max over streams) / K: the same kernel under the stream '
+                                                  'overlap of the timed region; <= ms_per_step',
+                     'bytes_per_frame': BYTES_PER_FRAME_ALL, 'frames_per_launch': B * T,
+                     'mfcc_only_kernel': {'kernel': 'MFCC-only kernel (dsp_features_batch, DSP_OUT_MFCC -> [sum T, 13]), the '
+                                                    'kernel rounds 1-2 reported', 'kernel_ms': mfcc_only_ms,
+                                          'bytes_per_frame': BYTES_PER_FRAME_MFCC,
+                                          'achieved': BYTES_PER_FRAME_MFCC * B * T / (mfcc_only_ms * 1e-3) / 1e9,
+                                          'frac': BYTES_PER_FRAME_MFCC * B * T / (mfcc_only_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
                      'whole_step_GBps': BYTES_PER_FRAME_ALL * value / world / 1e9,
                      'compute': compute_roof(kernel_ms)},
         'parity_normwise_vs_oracle': parity,

@@ -46,9 +46,12 @@ def local_slice(sample_offsets, world, rank):
 def gather_features(local, group=None, dst=None):
     """Gather variable-length [n_r, D] feature tensors from every rank.
 
-    One small all_gather of the row counts, then ONE all_gather_into_tensor of the payload padded to
-    the largest count (per-link bound on xGMI: fewer, larger collectives).  Returns (rows, counts)
-    with rows = concatenation in rank order; if `dst` is given only that rank returns rows.
+    One small all_gather of the row counts, then
+      * dst is None: ONE all_gather_into_tensor of the payload padded to the largest count (per-link bound on
+        xGMI: fewer, larger collectives) -- every rank returns the rows of all ranks in rank order;
+      * dst = r: a real gather (BASELINE.json configs[2], "RCCL gather of MFCC tensors"): every other rank SENDS
+        exactly its rows and rank r receives them straight into their place in the result (one grouped
+        send/recv, no padding, no staging copy); the other ranks receive nothing and return (None, counts).
     """
     import torch
     import torch.distributed as dist
@@ -60,6 +63,26 @@ def gather_features(local, group=None, dst=None):
     mine = torch.tensor([n_local], dtype=torch.int64, device=local.device)
     dist.all_gather_into_tensor(counts, mine, group=group)
     counts_h = [int(c) for c in counts.cpu()]
+    if dst is not None:
+        local = local.contiguous()
+        if rank != dst:
+            if n_local > 0:
+                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, local, _global_rank(dst, group), group)]):
+                    w.wait()
+            return None, counts_h
+        rows = torch.empty((sum(counts_h), D), dtype=local.dtype, device=local.device)
+        ops, at = [], 0
+        for r in range(world):
+            part = rows[at:at + counts_h[r]]
+            if r == rank:
+                part.copy_(local)
+            elif counts_h[r] > 0:
+                ops.append(dist.P2POp(dist.irecv, part, _global_rank(r, group), group))
+            at += counts_h[r]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return rows, counts_h
     n_max = max(counts_h)
     padded = local
     if n_local < n_max:
@@ -67,11 +90,14 @@ def gather_features(local, group=None, dst=None):
         padded[:n_local] = local
     buf = torch.empty((world * n_max, D), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(buf, padded.contiguous(), group=group)
-    if dst is not None and rank != dst:
-        return None, counts_h
     buf = buf.view(world, n_max, D)
     rows = torch.cat([buf[r, :counts_h[r]] for r in range(world)], dim=0)
     return rows, counts_h
+
+
+def _global_rank(group_rank, group):
+    import torch.distributed as dist
+    return group_rank if group is None else dist.get_global_rank(group, group_rank)
 
 
 def extract_sharded(compute, waves, sample_offsets, group=None, gather=True):

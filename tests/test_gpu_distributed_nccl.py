@@ -96,13 +96,13 @@ def test_bench_refuses_more_ranks_than_devices():
 
 def test_bench_gpus_flag_is_honoured_without_a_gpu():
     """On the CPU container there are 0 devices: `--gpus 2` must fail loudly, never report n_gpus=1."""
+    import torch
+    if torch.cuda.device_count() >= 2:       # decided BEFORE spawning: with two GPUs the full default bench would run
+        pytest.skip('two GPUs visible: the launcher would really run')
     env = dict(os.environ)
     env.pop('WORLD_SIZE', None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], capture_output=True,
                        text=True, timeout=300, env=env)
-    import torch
-    if torch.cuda.device_count() >= 2:
-        pytest.skip('two GPUs visible: the launcher would really run')
     assert r.returncode != 0 and 'requested but only' in r.stderr
 
 

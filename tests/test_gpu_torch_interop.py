@@ -1,7 +1,8 @@
 """Next-row f-3: the GPU front-end feeds a PyTorch-ROCm recurrent classifier without a
-host round trip.  The reference ships no weights or data, so the check is logits parity on seeded
-random weights: the same classifier fed (a) features from the HIP kernels, resident on the device,
-and (b) features from the fp64 oracle."""
+host round trip.  The reference ships no weights or data (accuracy parity is unpinned and stays so), so the
+check is logits parity on seeded weights: a classifier whose forward pass is pinned to the reference's own class
+(tests/test_classifier_golden.py) fed (a) features from the HIP kernels, resident on the device, and (b) features
+from the fp64 oracle."""
 import numpy as np
 import pytest
 
@@ -14,23 +15,15 @@ CFG = dict(samplerate=16000, winlen=0.025, winstep=0.01, numcep=13, nfilt=40, nf
 
 
 def _classifier(torch):
-    """Same shape as the reference's vanilla `RNN` head (rnn_clf.py:12-34): bidirectional GRU over
-    [T, B, 39], directions summed, average + max pooling over time, Linear(2H -> 20)."""
-    class Clf(torch.nn.Module):
-        def __init__(self, d=39, h=200, classes=20):
-            super().__init__()
-            self.gru = torch.nn.GRU(d, h, bidirectional=True)
-            self.out = torch.nn.Linear(2 * h, classes)
-            self.h = h
-
-        def forward(self, inp, lens):
-            y, _ = self.gru(inp)                                   # [T, B, 2H]
-            y = y[..., :self.h] + y[..., self.h:]
-            mask = (torch.arange(inp.shape[0], device=inp.device)[:, None] < lens[None, :]).unsqueeze(-1)
-            avg = (y * mask).sum(0) / lens[:, None]
-            mx = y.masked_fill(~mask, -1e30).max(0).values
-            return self.out(torch.cat([avg, mx], dim=1))
-    return Clf()
+    """features/classifier.py::RNNHead -- the forward pass of the reference's `RNN` (rnn_clf.py:12-34 over
+    layers.py:42-76), pinned to logits of the REAL reference class by tests/test_classifier_golden.py -- with the
+    fixture's seeded weights."""
+    import os
+    from features.classifier import RNNHead, fill_parameters
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'rnn_golden.npz'))
+    head = RNNHead()
+    fill_parameters(head, int(g['seed']))
+    return head
 
 
 def test_device_features_feed_torch_rnn():
@@ -56,9 +49,8 @@ def test_device_features_feed_torch_rnn():
         ref_inp[:n, b] = r[:n]
         assert len0[b] == n
     assert np.max(np.abs(inp.cpu().numpy() - ref_inp)) <= 1e-4 * np.max(np.abs(ref_inp))
-    torch.manual_seed(0)
     clf = _classifier(torch).to(dev).eval()
-    lens_t = torch.as_tensor(len0, device=dev)
+    lens_t = np.asarray(len0)
     with torch.no_grad():
         logits_gpu = clf(inp, lens_t).cpu().numpy()
         logits_ref = clf(torch.from_numpy(ref_inp).to(dev), lens_t).cpu().numpy()
