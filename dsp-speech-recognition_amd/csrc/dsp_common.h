@@ -34,6 +34,11 @@ struct BatchGeom {
     int64_t uniform_frames;     // frames per utterance when uniform
     int64_t total_frames;
     int32_t n_utt;
+    // ragged batches only, both optional: utterance b is samples [seg[2b], seg[2b+1]) OF the range sample_off names
+    // (endpoint-trimmed clips read in place), and per-utterance (sum (x - x0), sum (x - x0)^2) accumulators, x0 = the
+    // segment's first sample (fp64 atomics; the unit-variance statistics of model.py:62-63)
+    const int64_t* seg;
+    double* stats;
 };
 
 // Largest b with off[b] <= g  (off is non-decreasing, off[0] == 0, off[n] == total > g).

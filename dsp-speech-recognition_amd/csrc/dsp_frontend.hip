@@ -87,6 +87,8 @@ BatchGeom make_geom(const int64_t* d_sample_offsets, const int64_t* d_frame_offs
     }
     bg.total_frames = n_frames_total;
     bg.n_utt = n_utt;
+    bg.seg = nullptr;
+    bg.stats = nullptr;
     return bg;
 }
 
@@ -623,6 +625,87 @@ int dsp_trim_scale_batch(const void* d_wave, int wave_dtype, const int64_t* d_sa
         trim_scale_kernel<DSP_WAVE_F32><<<n_utt, 256, 0, st>>>(d_wave, d_sample_offsets, d_segments, d_dst_offsets, unit_variance, d_out);
     else
         return fail(DSP_EINVAL, "unsupported wave_dtype %d", wave_dtype);
+    HIP_TRY(hipGetLastError());
+    return DSP_OK;
+}
+
+namespace {
+struct SegWork {
+    size_t stats, tile, goff, gutt, cep, total;
+};
+// layout of the caller-owned work buffer of dsp_mfcc_delta_segments_batch (every part 256-byte aligned)
+SegWork seg_work_layout(int32_t n_utt, int64_t n_frames_bound, int32_t C) {
+    auto pad = [](size_t b) { return (b + 255) / 256 * 256; };
+    SegWork w;
+    w.stats = 0;
+    w.tile = w.stats + pad((size_t)n_utt * 2 * sizeof(double));
+    w.goff = w.tile + pad(((size_t)n_utt + 1) * sizeof(int64_t));
+    w.gutt = w.goff + pad(((size_t)n_utt + 1) * sizeof(int32_t));
+    w.cep = w.gutt + pad(((size_t)(n_frames_bound >> 3) + (size_t)n_utt) * sizeof(int32_t));
+    w.total = w.cep + pad((size_t)n_frames_bound * (size_t)C * sizeof(float));
+    return w;
+}
+}  // namespace
+
+int dsp_segments_workspace_bytes(const dsp_plan* plan, int32_t n_utt, int64_t n_frames_bound, size_t* bytes) {
+    if (!plan || !bytes || n_utt <= 0 || n_frames_bound <= 0) return fail(DSP_EINVAL, "dsp_segments_workspace_bytes: bad arguments");
+    *bytes = seg_work_layout(n_utt, n_frames_bound, plan->C).total;
+    return DSP_OK;
+}
+
+int dsp_mfcc_delta_segments_batch(const dsp_plan* plan, const void* d_wave, int wave_dtype,
+                                  const int64_t* d_sample_offsets, const int64_t* d_segments,
+                                  const int64_t* d_frame_offsets, int32_t n_utt, int64_t n_frames_bound,
+                                  int32_t delta_n, int32_t unit_variance, void* d_work, size_t work_bytes,
+                                  float* d_out, void* stream) {
+    if (!plan || !d_out || !d_work || !d_segments) return fail(DSP_EINVAL, "dsp_mfcc_delta_segments_batch: NULL argument");
+    if (delta_n < 1) return fail(DSP_EINVAL, "N must be an integer >= 1");  // base.py:71-72
+    int rc = check_geom(d_wave, wave_dtype, d_sample_offsets, d_frame_offsets, n_utt, n_frames_bound, 0);
+    if (rc != DSP_OK) return rc;
+    {
+        int dev = -1;
+        HIP_TRY(hipGetDevice(&dev));
+        if (dev != plan->device) return fail(DSP_EINVAL, "plan belongs to device %d, current device is %d", plan->device, dev);
+    }
+    const int C = plan->C;
+    const size_t lds = ((size_t)(DT_TILE + 4 * delta_n) + (size_t)(DT_TILE + 2 * delta_n)) * C * sizeof(float);
+    BatchGeom bg = make_geom(d_sample_offsets, d_frame_offsets, n_utt, n_frames_bound, 0, plan->L, plan->S);
+    // Served by the NFFT = 512 kernel on buffers it can read in place; everything else (and unit variance without
+    // appendEnergy, where the scaling does not reduce to a shift of c0) reports 1: "use the trimmed-copy path".
+    if (g_force_generic || !plan->d_fast || C <= 0 || lds > 64 * 1024 || !fast512_applicable(plan, bg, d_wave, wave_dtype) ||
+        (unit_variance && !plan->append_energy) || (n_frames_bound >> 3) + n_utt > 0x3fffffff)
+        return 1;
+    const SegWork w = seg_work_layout(n_utt, n_frames_bound, C);
+    if (work_bytes < w.total) return fail(DSP_EINVAL, "work buffer too small (%zu < %zu bytes)", work_bytes, w.total);
+    hipStream_t st = (hipStream_t)stream;
+    char* wp = static_cast<char*>(d_work);
+    double* stats = unit_variance ? reinterpret_cast<double*>(wp + w.stats) : nullptr;
+    int64_t* tile_off = reinterpret_cast<int64_t*>(wp + w.tile);
+    DspRaggedTables pre;
+    pre.shift = 3;
+    pre.group_off = reinterpret_cast<int32_t*>(wp + w.goff);
+    pre.group_utt = reinterpret_cast<int32_t*>(wp + w.gutt);
+    float* cep = reinterpret_cast<float*>(wp + w.cep);
+    // one small launch: group tables of the MFCC kernel, tile table of the delta pass, statistics zeroed
+    f512_build_group_tables(d_frame_offsets, n_utt, 3, pre.group_off, pre.group_utt, st, tile_off, stats);
+    bg.seg = d_segments;
+    bg.stats = stats;
+    rc = fast512_launch(plan, d_wave, wave_dtype, bg, cep, (int64_t)C, st, &pre);
+    if (rc != DSP_OK) return fail(rc < 0 ? rc : DSP_EHIP, "fused kernel launch failed");
+    BatchGeom dg;
+    memset(&dg, 0, sizeof(dg));
+    dg.frame_off = d_frame_offsets;
+    dg.total_frames = n_frames_bound;
+    dg.n_utt = n_utt;
+    int den = 0;
+    for (int i = 1; i <= delta_n; ++i) den += i * i;
+    const float inv_den = (float)(1.0 / (2.0 * den));
+    const int64_t blocks = n_frames_bound / DT_TILE + n_utt;
+    if (blocks > 0x7fffffff) return fail(DSP_EINVAL, "too many delta tiles");
+    if (C == 13)
+        delta_rows_kernel<13><<<(int)blocks, 256, lds, st>>>(cep, dg, C, delta_n, inv_den, d_out, 0, tile_off, d_segments, stats);
+    else
+        delta_rows_kernel<0><<<(int)blocks, 256, lds, st>>>(cep, dg, C, delta_n, inv_den, d_out, 0, tile_off, d_segments, stats);
     HIP_TRY(hipGetLastError());
     return DSP_OK;
 }

@@ -261,6 +261,11 @@ __device__ __forceinline__ F512Group f512_locate(const F512Params& P, const Batc
         g.t0 = (G - P.group_off[g.utt]) * 8;
         g.s0 = bg.sample_off[g.utt];
         g.nsamp = (int)(bg.sample_off[g.utt + 1] - g.s0);
+        if (bg.seg != nullptr) {   // the utterance is a segment of that range, read in place
+            const int64_t lo = bg.seg[2 * g.utt];
+            g.nsamp = (int)(bg.seg[2 * g.utt + 1] - lo);
+            g.s0 += lo;
+        }
         g.row0 = bg.frame_off[g.utt];
         g.T = (int)(bg.frame_off[g.utt + 1] - g.row0);
         g.nf1 = 8;
@@ -463,6 +468,19 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         const bool fast_stage = (NSTAGE * 256 <= F512_WAVE_FLOATS) && grp.nf1 == 8 && base + NSTAGE * 256 <= nsamp;
         const int d = (RAGGED && !fast_stage) ? (int)(g0 & 3) : 0;   // LDS image starts d samples earlier (aligned)
 
+        // Unit-variance statistics of segments read in place (bg.stats): every group adds the sums of its own share
+        // [base, base + 8 S) of the utterance -- the last group takes everything up to the end -- of (x - x0) and
+        // (x - x0)^2, x0 = the utterance's first sample (shift-invariant, and no cancellation under a DC offset).
+        float st_s = 0.f, st_q = 0.f, st_ref = 0.f;
+        int st_lim = 0;
+        bool do_stats = false;
+        if constexpr (RAGGED) {
+            do_stats = bg.stats != nullptr && nsamp > 0;
+            if (do_stats) {
+                st_ref = dsp_load_sample<DTYPE>(wave, grp.s0);
+                st_lim = t0 + 8 >= T ? nsamp : base + 8 * P.S;
+            }
+        }
         // ---- stage 7 S + L (+ d) samples: coalesced aligned 16 B loads, all issued before first use;
         //      pre-emphasis, zero fill outside the utterance. ----
         if (fast_stage) {
@@ -503,6 +521,17 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
                     y.z = fmaf(-P.preemph, x[1], x[2]);
                     y.w = fmaf(-P.preemph, x[2], x[3]);
                     *reinterpret_cast<float4*>(wbuf + 4 * lane + 256 * r) = y;
+                    if constexpr (RAGGED) {
+                        if (do_stats) {
+                            const int left_in_share = st_lim - (base + 4 * lane + 256 * r);   // samples of this vector inside
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float dl = k < left_in_share ? x[k] - st_ref : 0.f;
+                                st_s += dl;
+                                st_q = fmaf(dl, dl, st_q);
+                            }
+                        }
+                    }
                 }
             }
         } else if (!RAGGED) {
@@ -576,6 +605,15 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
                     y.z = fmaf(-P.preemph, x[1], x[2]);
                     y.w = fmaf(-P.preemph, x[2], x[3]);
                     if constexpr (RAGGED) {
+                        if (do_stats) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const bool in = v < span_vec && rel + k >= base && rel + k < st_lim;
+                                const float dl = in ? x[k] - st_ref : 0.f;
+                                st_s += dl;
+                                st_q = fmaf(dl, dl, st_q);
+                            }
+                        }
                         // the utterance may start / end inside this vector: first sample is not filtered,
                         // everything outside [0, nsamp) is zero
                         if (rel + 0 == 0) y.x = x[0];
@@ -595,6 +633,15 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
                     }
                     // rounds past the span write zeros inside this wave's own buffer when it is large enough
                     if (NSTAGE * 256 <= F512_WAVE_FLOATS || v < span_vec) *reinterpret_cast<float4*>(wbuf + 4 * v) = y;
+                }
+            }
+        }
+        if constexpr (RAGGED) {
+            if (do_stats) {
+                const float ws = dsp_wave_sum(st_s), wq = dsp_wave_sum(st_q);
+                if (lane == 0) {
+                    unsafeAtomicAdd(bg.stats + 2 * utt, (double)ws);
+                    unsafeAtomicAdd(bg.stats + 2 * utt + 1, (double)wq);
                 }
             }
         }
@@ -1014,7 +1061,8 @@ __global__ __launch_bounds__(1024) void f512_group_prefix_kernel(const int64_t* 
                                                                  int32_t shift, int32_t* __restrict__ group_off,
                                                                  int32_t* __restrict__ group_utt = nullptr,
                                                                  int32_t tile_shift = 0,
-                                                                 int64_t* __restrict__ tile_off = nullptr) {
+                                                                 int64_t* __restrict__ tile_off = nullptr,
+                                                                 double* __restrict__ zero_stats = nullptr) {
     // optional second table in the same launch: tile_off[b] = sum_{i<b} ceil(T_i / 2^tile_shift) (the delta pass)
     __shared__ int32_t wsum[16], wsum_t[16];
     const int tid = threadIdx.x;
@@ -1026,6 +1074,7 @@ __global__ __launch_bounds__(1024) void f512_group_prefix_kernel(const int64_t* 
         const int64_t T = frame_off[b + 1] - frame_off[b];
         sum += (int32_t)((T + rnd) >> shift);
         sum_t += (int32_t)((T + rnd_t) >> tile_shift);
+        if (zero_stats != nullptr) { zero_stats[2 * b] = 0.0; zero_stats[2 * b + 1] = 0.0; }
     }
     // inclusive scan of the per-thread sums: inside each wave with shuffles, across the 16 waves through LDS
     int32_t inc = sum, inc_t = sum_t;
@@ -1070,7 +1119,7 @@ __global__ __launch_bounds__(1024) void f512_group_prefix_kernel(const int64_t* 
 // Builds both ragged index tables on `st`: one launch for small batches, prefix + parallel fill otherwise.
 static inline void f512_build_group_tables(const int64_t* frame_off, int32_t n_utt, int32_t shift,
                                            int32_t* group_off, int32_t* group_utt, hipStream_t st,
-                                           int64_t* tile_off = nullptr);
+                                           int64_t* tile_off = nullptr, double* zero_stats = nullptr);
 
 __global__ __launch_bounds__(256) void f512_group_fill_kernel(const int32_t* __restrict__ group_off, int32_t n_utt,
                                                               int32_t* __restrict__ group_utt) {
@@ -1080,12 +1129,12 @@ __global__ __launch_bounds__(256) void f512_group_fill_kernel(const int32_t* __r
 
 static inline void f512_build_group_tables(const int64_t* frame_off, int32_t n_utt, int32_t shift,
                                            int32_t* group_off, int32_t* group_utt, hipStream_t st,
-                                           int64_t* tile_off) {
+                                           int64_t* tile_off, double* zero_stats) {
     if (n_utt <= 4096) {
-        f512_group_prefix_kernel<<<1, 1024, 0, st>>>(frame_off, n_utt, shift, group_off, group_utt, DT_SHIFT, tile_off);
+        f512_group_prefix_kernel<<<1, 1024, 0, st>>>(frame_off, n_utt, shift, group_off, group_utt, DT_SHIFT, tile_off, zero_stats);
         return;
     }
-    f512_group_prefix_kernel<<<1, 1024, 0, st>>>(frame_off, n_utt, shift, group_off, nullptr, DT_SHIFT, tile_off);
+    f512_group_prefix_kernel<<<1, 1024, 0, st>>>(frame_off, n_utt, shift, group_off, nullptr, DT_SHIFT, tile_off, zero_stats);
     const int fill_blocks = (int)((n_utt + 255) / 256 < 1024 ? (n_utt + 255) / 256 : 1024);
     f512_group_fill_kernel<<<fill_blocks, 256, 0, st>>>(group_off, n_utt, group_utt);
 }

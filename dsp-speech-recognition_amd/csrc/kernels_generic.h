@@ -331,11 +331,15 @@ template <int DC>
 __global__ __launch_bounds__(256) void delta_rows_kernel(const float* __restrict__ in, BatchGeom bg, int32_t D_rt,
                                                          int32_t N, float inv_den, float* __restrict__ out,
                                                          int32_t tiles_per_utt_uniform,
-                                                         const int64_t* __restrict__ tile_off) {
+                                                         const int64_t* __restrict__ tile_off,
+                                                         const int64_t* __restrict__ seg = nullptr,
+                                                         const double* __restrict__ stats = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float smem_d[];
+    __shared__ float s_shift;
     const int D = DC > 0 ? DC : D_rt;
     int64_t base;
     int T, tile;
+    if (threadIdx.x == 0) s_shift = 0.f;
     if (bg.uniform_frames > 0) {
         const int u = (int)blockIdx.x / tiles_per_utt_uniform;
         tile = (int)blockIdx.x - u * tiles_per_utt_uniform;
@@ -347,6 +351,18 @@ __global__ __launch_bounds__(256) void delta_rows_kernel(const float* __restrict
         tile = (int32_t)(blockIdx.x - tile_off[u]);
         base = bg.frame_off[u];
         T = (int)(bg.frame_off[u + 1] - base);
+        // Segments read in place (dsp_mfcc_delta_segments_batch, unit variance): the cepstra are those of the UNSCALED
+        // clip.  Dividing the clip by its standard deviation sd scales every power by 1 / sd^2, i.e. adds -ln sd^2 to
+        // every log: the cepstra k >= 1 do not move (their DCT rows sum to zero), c0 = log(energy) loses ln(var) --
+        // unless the frame's energy was exactly zero (then it is ln(eps) either way, base.py:26).  model.py:62-63.
+        if (stats != nullptr && threadIdx.x == 0) {
+            const double n = (double)(seg[2 * u + 1] - seg[2 * u]);
+            if (n > 0.0) {
+                const double mean = stats[2 * u] / n;
+                const double var = stats[2 * u + 1] / n - mean * mean;
+                s_shift = var > 0.0 ? (float)log(var) : 0.f;       // zero variance: sklearn scales by 1
+            }
+        }
     }
     const int t0 = tile * DT_TILE;
     const int nt = (T - t0) < DT_TILE ? (T - t0) : DT_TILE;
@@ -389,7 +405,9 @@ __global__ __launch_bounds__(256) void delta_rows_kernel(const float* __restrict
         float acc = 0.f;
         for (int n = 1; n <= N; ++n) acc = fmaf((float)n, sd[(r + N + n) * D + d] - sd[(r + N - n) * D + d], acc);
         float* o = out_u + r * 3 * D + d;
-        o[0] = sx[(r + 2 * N) * D + d];
+        float x0 = sx[(r + 2 * N) * D + d];
+        if (d == 0 && x0 != -36.04365338911715f) x0 -= s_shift;
+        o[0] = x0;
         o[D] = sd[(r + N) * D + d];
         o[2 * D] = acc * inv_den;
     }

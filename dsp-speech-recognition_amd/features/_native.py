@@ -61,6 +61,9 @@ SIGNATURES = {
     'dsp_scale_columns': (C.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp]),
     'dsp_vad_features_batch': (C.c_int, [c_vp, C.c_int, c_vp, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32,
                                          c_i32, c_vp, c_vp, c_vp]),
+    'dsp_segments_workspace_bytes': (C.c_int, [c_vp, c_i32, c_i64, C.POINTER(C.c_size_t)]),
+    'dsp_mfcc_delta_segments_batch': (C.c_int, [c_vp, c_vp, C.c_int, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32,
+                                                c_vp, C.c_size_t, c_vp, c_vp]),
     'dsp_trim_scale_batch': (C.c_int, [c_vp, C.c_int, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     'dsp_endpoint_rule_batch': (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_f64, c_f64, c_vp, c_vp]),
     'dsp_endpoint_layout_batch': (C.c_int, [c_vp, c_vp, c_i32, c_f64, c_f64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),

@@ -5,8 +5,10 @@ feature_extract_mfcc).
     waveforms (ragged, int16 or fp32)
       -> per-frame amplitude + ZCR, two-threshold rule        (dsp_vad_features_batch, dsp_endpoint_rule_batch)
       -> [left, right) in samples, trimmed-batch offsets       (dsp_endpoint_layout_batch, on the device)
-      -> trimmed (optionally unit-variance) copy               (dsp_trim_scale_batch)
-      -> MFCC (+ delta, delta-delta) of the trimmed clips      (dsp_mfcc_delta_batch, ragged fast path)
+      -> MFCC + delta + delta-delta of sig[left:right] read IN PLACE; unit variance = a shift of c0 from fp64 sums
+         the feature kernel accumulates while staging            (dsp_mfcc_delta_segments_batch)
+         [plans / buffers that path does not serve, and delta_n = 0: trimmed (optionally unit-variance) fp32 copy
+          (dsp_trim_scale_batch) -> dsp_mfcc_delta_batch / dsp_features_batch]
 
 Nothing comes back to the host in the middle: the frame-index -> sample-index conversion
 (endpoint.py:64), the clipping and both prefix sums run in one small kernel, and the feature kernels
@@ -91,8 +93,21 @@ class PipelineLayout:
         self.d_seg = nat.DeviceBuffer(B * 16)
         self.d_dst_off = nat.DeviceBuffer((B + 1) * 8)
         self.d_frame_off = nat.DeviceBuffer((B + 1) * 8)
-        self.d_trim = nat.DeviceBuffer(max(self.total_samples, 1) * 4)
+        self._d_trim = None                      # fp32 copy of the trimmed clips: only the fallback path needs it
         self.features = _DeviceLayout(B, self.d_dst_off, self.d_frame_off, self.frames_bound)
+        # scratch of the in-place path (dsp_mfcc_delta_segments_batch): tables, statistics, dense cepstra
+        self.d_work = None
+        if delta_n >= 1:
+            import ctypes as C
+            nbytes = C.c_size_t(0)
+            nat.check(nat.load().dsp_segments_workspace_bytes(fp.plan.handle, B, max(self.frames_bound, 1), C.byref(nbytes)))
+            self.d_work = nat.DeviceBuffer(int(nbytes.value))
+
+    @property
+    def d_trim(self):
+        if self._d_trim is None:
+            self._d_trim = nat.DeviceBuffer(max(self.total_samples, 1) * 4)
+        return self._d_trim
 
 
 class VadMfccPipeline:
@@ -102,6 +117,7 @@ class VadMfccPipeline:
         mfcc_kwargs.setdefault('samplerate', rate)
         self.rate = rate
         self.unit_variance = bool(unit_variance)
+        self.copy_trimmed = False       # True: always go through the trimmed fp32 copy (A/B and tests)
         self.endpoint = EndpointPlan(rate, frame, step)
         self.features = FeaturePlan(**mfcc_kwargs)
         self._tls = threading.local()   # per thread: last few batch shapes seen by run()
@@ -138,6 +154,16 @@ class VadMfccPipeline:
         nat.check(lib.dsp_endpoint_layout_batch(lay.d_ep.ptr, lay.vad.p_sample, lay.n_utt, float(ep.step),
                                                 float(ep.rate), fp.L, fp.S, d_jitter, lay.d_seg.ptr,
                                                 lay.d_dst_off.ptr, lay.d_frame_off.ptr, st))
+        if lay.d_work is not None and not self.copy_trimmed:
+            # the feature kernel reads sig[left:right] where it lies; unit variance becomes a shift of c0
+            rc = lib.dsp_mfcc_delta_segments_batch(fp.plan.handle, d_wave, wave_dtype, lay.vad.p_sample, lay.d_seg.ptr,
+                                                   lay.d_frame_off.ptr, lay.n_utt, max(lay.frames_bound, 1), lay.delta_n,
+                                                   1 if self.unit_variance else 0, lay.d_work.ptr, lay.d_work.nbytes,
+                                                   d_out, st)
+            if rc == nat.OK:
+                return
+            if rc != 1:                      # 1 = "not served in place": take the copy below
+                nat.check(rc)
         nat.check(lib.dsp_trim_scale_batch(d_wave, wave_dtype, lay.vad.p_sample, lay.d_seg.ptr, lay.d_dst_off.ptr,
                                            lay.n_utt, 1 if self.unit_variance else 0, lay.d_trim.ptr, st))
         fp.run_raw(lay.d_trim.ptr, nat.WAVE_F32, lay.features, d_out, lay.delta_n, st)

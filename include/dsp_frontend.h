@@ -188,6 +188,27 @@ int dsp_trim_scale_batch(const void* d_wave, int wave_dtype, const int64_t* d_sa
                          int32_t unit_variance, float* d_out, void* stream);
 
 /*
+ * configs[3] without the trimmed copy: MFCC | delta | delta-delta of sig[left:right] for every utterance of a ragged
+ * batch, READ IN PLACE -- model.py:113-121 (endpoint_detect -> scale -> feature_extract_mfcc) without writing and
+ * re-reading an fp32 copy of every clip.  d_segments = int64 [B, 2] (left, right) relative to each utterance's start
+ * (dsp_endpoint_layout_batch writes them), d_frame_offsets = the frame prefix of the TRIMMED clips (same call),
+ * n_frames_bound >= their total.  unit_variance != 0: the clip counts as divided by its population standard deviation
+ * (sklearn scale(with_mean=False), model.py:62-63) -- computed as what that scaling does to the result: it adds
+ * -ln(var) to c0 = log(energy) and leaves every other cepstrum, delta and delta-delta unchanged; var comes from fp64
+ * sums the MFCC kernel accumulates while it stages the samples.  d_work: caller-owned scratch of
+ * dsp_segments_workspace_bytes() bytes (tables, statistics, dense cepstra): no pooled workspace, no allocation, the call
+ * is a fixed sequence of three launches on `stream` and can be captured into a HIP graph.
+ * Returns 1 (not an error) when the plan / buffer is not served in place (no NFFT = 512 fast path, misaligned buffer,
+ * unit variance without appendEnergy): use dsp_trim_scale_batch + dsp_mfcc_delta_batch then.
+ */
+int dsp_segments_workspace_bytes(const dsp_plan* plan, int32_t n_utt, int64_t n_frames_bound, size_t* bytes);
+int dsp_mfcc_delta_segments_batch(const dsp_plan* plan, const void* d_wave, int wave_dtype,
+                                  const int64_t* d_sample_offsets, const int64_t* d_segments,
+                                  const int64_t* d_frame_offsets, int32_t n_utt, int64_t n_frames_bound,
+                                  int32_t delta_n, int32_t unit_variance, void* d_work, size_t work_bytes,
+                                  float* d_out, void* stream);
+
+/*
  * Device-side glue between dsp_endpoint_rule_batch and dsp_trim_scale_batch / dsp_features_batch, so that
  * the endpoint -> trim -> features pipeline of model.py:113-121 needs no host round trip:
  *   d_segments[2b], [2b+1] = int((left * cfg.step) * rate), int((right * cfg.step) * rate) in fp64, that

@@ -304,18 +304,23 @@ def test_vad_tile_kernel_vs_per_frame_kernel_and_oracle(rate, dtype):
         assert list(tile[1][fo_r[b]:fo_r[b + 1]]) == list(dsp_oracle.get_zcr(frames))
 
 
+@pytest.mark.parametrize('copy_trimmed', [False, True], ids=['in_place', 'trimmed_copy'])
 @pytest.mark.parametrize('unit_variance', [False, True])
-def test_config4_vad_trim_mfcc_pipeline(unit_variance):
+def test_config4_vad_trim_mfcc_pipeline(unit_variance, copy_trimmed):
     """configs[3]: endpointing -> trim (-> unit variance, model.py:63) -> MFCC+delta+delta2 with
-    variable-length outputs, against the oracle run utterance by utterance."""
+    variable-length outputs, against the oracle run utterance by utterance.  Both forms of the feature stage:
+    sig[left:right] read in place (unit variance as a shift of c0 from in-kernel fp64 sums,
+    dsp_mfcc_delta_segments_batch) and the trimmed / scaled fp32 copy (dsp_trim_scale_batch)."""
     from features.pipeline import VadMfccPipeline
     from golden_cases import make_signal
     clips = [make_signal(('vad', 200 + i, 16000 + 1700 * i)) for i in range(10)]
     clips.append(make_signal(('int16', 77, 9000)))      # no burst: whole-clip fallback
     clips.append(make_signal(('bursts', 78, 32000)))
+    clips.append((make_signal(('vad', 300, 20000)).astype(np.int32) + 6000).clip(-32768, 32767).astype(np.int16))  # DC offset >> noise floor
     so = np.concatenate([[0], np.cumsum([len(c) for c in clips])]).astype(np.int64)
     pipe = VadMfccPipeline(rate=16000, unit_variance=unit_variance, winfunc=np.hamming,
                            **{k: v for k, v in CFG.items() if k != 'samplerate'})
+    pipe.copy_trimmed = copy_trimmed
     out, fo, ends = pipe.run(np.concatenate(clips), so, delta_n=2)
     assert fo[-1] == out.shape[0] and out.shape[1] == 39
     for b, c in enumerate(clips):
