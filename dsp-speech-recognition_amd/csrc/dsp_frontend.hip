@@ -581,10 +581,84 @@ int dsp_scale_columns(float* d_x, int64_t rows, int32_t cols, const float* d_sca
     return DSP_OK;
 }
 
+}  // extern "C"
+
+// A batch shape's index tables, built once (include/dsp_frontend.h: dsp_layout).
+struct dsp_layout {
+    int32_t n_utt, frame_len, frame_step, shift;
+    int64_t n_frames_total;
+    int32_t* group_off;
+    int32_t* group_utt;
+    int device;
+};
+
+static int vad_features_impl(const dsp_layout* layout, const void* d_wave, int wave_dtype, const int64_t* d_sample_offsets,
+                             const int64_t* d_frame_offsets, int32_t n_utt, int64_t n_frames_total,
+                             int64_t uniform_samples, int32_t frame_len, int32_t frame_step, int32_t use_sq,
+                             double* d_amp_sum, int32_t* d_zcr, void* stream);
+
+extern "C" {
+
+int dsp_layout_create(const int64_t* d_frame_offsets, int32_t n_utt, int64_t n_frames_total, int32_t frame_len,
+                      int32_t frame_step, void* stream, dsp_layout** out) {
+    if (!out) return fail(DSP_EINVAL, "dsp_layout_create: out is NULL");
+    *out = nullptr;
+    if (!d_frame_offsets || n_utt <= 0 || n_frames_total <= 0 || frame_len <= 0 || frame_step <= 0)
+        return fail(DSP_EINVAL, "dsp_layout_create: bad arguments");
+    const int tile = vad_tile_frames(frame_len, frame_step);
+    dsp_layout* l = new dsp_layout();
+    memset(l, 0, sizeof(*l));
+    l->n_utt = n_utt; l->frame_len = frame_len; l->frame_step = frame_step; l->n_frames_total = n_frames_total;
+    HIP_TRY(hipGetDevice(&l->device));
+    if (tile != 0) {
+        l->shift = tile == 16 ? 4 : 2;
+        const int64_t bound = n_frames_total / tile + n_utt;
+        if (bound > 0x3fffffff) { delete l; return fail(DSP_EINVAL, "dsp_layout_create: batch too large"); }
+        if (hipMalloc(reinterpret_cast<void**>(&l->group_off), ((size_t)n_utt + 1 + (size_t)bound) * sizeof(int32_t)) != hipSuccess) {
+            delete l;
+            return fail(DSP_EHIP, "dsp_layout_create: allocation failed");
+        }
+        l->group_utt = l->group_off + n_utt + 1;
+        f512_build_group_tables(d_frame_offsets, n_utt, l->shift, l->group_off, l->group_utt, (hipStream_t)stream);
+        if (hipGetLastError() != hipSuccess) { (void)hipFree(l->group_off); delete l; return fail(DSP_EHIP, "dsp_layout_create: launch failed"); }
+    }
+    *out = l;
+    return DSP_OK;
+}
+
+int dsp_layout_destroy(dsp_layout* layout) {
+    if (!layout) return DSP_OK;
+    if (layout->group_off) (void)hipFree(layout->group_off);
+    delete layout;
+    return DSP_OK;
+}
+
+int dsp_vad_features_layout_batch(const dsp_layout* layout, const void* d_wave, int wave_dtype,
+                                  const int64_t* d_sample_offsets, const int64_t* d_frame_offsets, int32_t use_sq,
+                                  double* d_amp_sum, int32_t* d_zcr, void* stream) {
+    if (!layout) return fail(DSP_EINVAL, "dsp_vad_features_layout_batch: layout is NULL");
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != layout->device) return fail(DSP_EINVAL, "layout belongs to device %d, current device is %d", layout->device, dev);
+    return vad_features_impl(layout, d_wave, wave_dtype, d_sample_offsets, d_frame_offsets, layout->n_utt,
+                             layout->n_frames_total, 0, layout->frame_len, layout->frame_step, use_sq, d_amp_sum, d_zcr,
+                             stream);
+}
+
 int dsp_vad_features_batch(const void* d_wave, int wave_dtype, const int64_t* d_sample_offsets,
                            const int64_t* d_frame_offsets, int32_t n_utt, int64_t n_frames_total,
                            int64_t uniform_samples, int32_t frame_len, int32_t frame_step, int32_t use_sq,
                            double* d_amp_sum, int32_t* d_zcr, void* stream) {
+    return vad_features_impl(nullptr, d_wave, wave_dtype, d_sample_offsets, d_frame_offsets, n_utt, n_frames_total,
+                             uniform_samples, frame_len, frame_step, use_sq, d_amp_sum, d_zcr, stream);
+}
+
+}  // extern "C"
+
+static int vad_features_impl(const dsp_layout* layout, const void* d_wave, int wave_dtype, const int64_t* d_sample_offsets,
+                             const int64_t* d_frame_offsets, int32_t n_utt, int64_t n_frames_total,
+                             int64_t uniform_samples, int32_t frame_len, int32_t frame_step, int32_t use_sq,
+                             double* d_amp_sum, int32_t* d_zcr, void* stream) {
     if (!d_amp_sum || !d_zcr) return fail(DSP_EINVAL, "dsp_vad_features_batch: NULL output");
     if (frame_len <= 0 || frame_step <= 0) return fail(DSP_EINVAL, "frame_len/frame_step must be > 0");
     int rc = check_geom(d_wave, wave_dtype, d_sample_offsets, d_frame_offsets, n_utt, n_frames_total, uniform_samples);
@@ -597,7 +671,11 @@ int dsp_vad_features_batch(const void* d_wave, int wave_dtype, const int64_t* d_
         const void* fw = d_wave;
         DspWorkspace* view = fused_kernel_view(fg, fw, wave_dtype, st);
         const bool ok = vad_tile_applicable(fg, fw, wave_dtype, tile);
-        if (ok) rc = vad_tile_launch(tile, frame_len, frame_step, use_sq, fg, fw, wave_dtype, d_amp_sum, d_zcr, st);
+        DspRaggedTables pre;
+        const bool have_pre = layout != nullptr && layout->group_off != nullptr && view == nullptr;
+        if (have_pre) { pre.shift = layout->shift; pre.group_off = layout->group_off; pre.group_utt = layout->group_utt; }
+        if (ok) rc = vad_tile_launch(tile, frame_len, frame_step, use_sq, fg, fw, wave_dtype, d_amp_sum, d_zcr, st,
+                                     have_pre ? &pre : nullptr);
         if (view && dsp_workspace_pool().release(view, st) != 0 && ok && rc == DSP_OK) rc = DSP_EHIP;
         if (ok) {
             if (rc != DSP_OK) return fail(rc, "vad tile kernel launch failed");
@@ -612,6 +690,8 @@ int dsp_vad_features_batch(const void* d_wave, int wave_dtype, const int64_t* d_
     HIP_TRY(hipGetLastError());
     return DSP_OK;
 }
+
+extern "C" {
 
 int dsp_trim_scale_batch(const void* d_wave, int wave_dtype, const int64_t* d_sample_offsets,
                          const int64_t* d_segments, const int64_t* d_dst_offsets, int32_t n_utt,
@@ -656,8 +736,9 @@ int dsp_segments_workspace_bytes(const dsp_plan* plan, int32_t n_utt, int64_t n_
 int dsp_mfcc_delta_segments_batch(const dsp_plan* plan, const void* d_wave, int wave_dtype,
                                   const int64_t* d_sample_offsets, const int64_t* d_segments,
                                   const int64_t* d_frame_offsets, int32_t n_utt, int64_t n_frames_bound,
-                                  int32_t delta_n, int32_t unit_variance, void* d_work, size_t work_bytes,
+                                  int32_t delta_n, int32_t flags, void* d_work, size_t work_bytes,
                                   float* d_out, void* stream) {
+    const int unit_variance = flags & DSP_SEG_UNIT_VARIANCE;
     if (!plan || !d_out || !d_work || !d_segments) return fail(DSP_EINVAL, "dsp_mfcc_delta_segments_batch: NULL argument");
     if (delta_n < 1) return fail(DSP_EINVAL, "N must be an integer >= 1");  // base.py:71-72
     int rc = check_geom(d_wave, wave_dtype, d_sample_offsets, d_frame_offsets, n_utt, n_frames_bound, 0);
@@ -686,8 +767,10 @@ int dsp_mfcc_delta_segments_batch(const dsp_plan* plan, const void* d_wave, int 
     pre.group_off = reinterpret_cast<int32_t*>(wp + w.goff);
     pre.group_utt = reinterpret_cast<int32_t*>(wp + w.gutt);
     float* cep = reinterpret_cast<float*>(wp + w.cep);
-    // one small launch: group tables of the MFCC kernel, tile table of the delta pass, statistics zeroed
-    f512_build_group_tables(d_frame_offsets, n_utt, 3, pre.group_off, pre.group_utt, st, tile_off, stats);
+    // one small launch: group tables of the MFCC kernel, tile table of the delta pass, statistics zeroed -- unless
+    // dsp_endpoint_layout_segments_batch has already left all of that in d_work
+    if (!(flags & DSP_SEG_TABLES_READY))
+        f512_build_group_tables(d_frame_offsets, n_utt, 3, pre.group_off, pre.group_utt, st, tile_off, stats);
     bg.seg = d_segments;
     bg.stats = stats;
     rc = fast512_launch(plan, d_wave, wave_dtype, bg, cep, (int64_t)C, st, &pre);
@@ -721,6 +804,25 @@ int dsp_endpoint_layout_batch(const int32_t* d_endpoints, const int64_t* d_sampl
     endpoint_layout_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(d_endpoints, d_sample_offsets, n_utt, cfg_step, rate,
                                                                frame_len, frame_step, d_jitter, d_segments,
                                                                d_dst_offsets, d_frame_offsets);
+    HIP_TRY(hipGetLastError());
+    return DSP_OK;
+}
+
+int dsp_endpoint_layout_segments_batch(const int32_t* d_endpoints, const int64_t* d_sample_offsets, int32_t n_utt,
+                                       double cfg_step, double rate, const int64_t* d_jitter, int64_t* d_segments,
+                                       int64_t* d_dst_offsets, int64_t* d_frame_offsets, const dsp_plan* plan,
+                                       int64_t n_frames_bound, void* d_work, size_t work_bytes, void* stream) {
+    if (!d_endpoints || !d_sample_offsets || !d_segments || !d_dst_offsets || !d_frame_offsets || !plan || !d_work || n_utt <= 0)
+        return fail(DSP_EINVAL, "dsp_endpoint_layout_segments_batch: bad arguments");
+    if (!(cfg_step > 0.0) || !(rate > 0.0) || n_frames_bound <= 0)
+        return fail(DSP_EINVAL, "dsp_endpoint_layout_segments_batch: step, rate, n_frames_bound must be > 0");
+    const SegWork w = seg_work_layout(n_utt, n_frames_bound, plan->C);
+    if (work_bytes < w.total) return fail(DSP_EINVAL, "work buffer too small (%zu < %zu bytes)", work_bytes, w.total);
+    char* wp = static_cast<char*>(d_work);
+    endpoint_layout_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(
+        d_endpoints, d_sample_offsets, n_utt, cfg_step, rate, plan->L, plan->S, d_jitter, d_segments, d_dst_offsets,
+        d_frame_offsets, 3, reinterpret_cast<int32_t*>(wp + w.goff), reinterpret_cast<int32_t*>(wp + w.gutt),
+        reinterpret_cast<int64_t*>(wp + w.tile), reinterpret_cast<double*>(wp + w.stats));
     HIP_TRY(hipGetLastError());
     return DSP_OK;
 }

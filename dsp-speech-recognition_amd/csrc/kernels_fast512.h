@@ -523,12 +523,19 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
                     *reinterpret_cast<float4*>(wbuf + 4 * lane + 256 * r) = y;
                     if constexpr (RAGGED) {
                         if (do_stats) {
-                            const int left_in_share = st_lim - (base + 4 * lane + 256 * r);   // samples of this vector inside
+                            const int round_in = st_lim - (base + 256 * r);    // samples of this round inside the share (wave-uniform)
+                            if (round_in >= 256) {                              // all of it: the common case, no masks
+                                const float d0 = x[0] - st_ref, d1 = x[1] - st_ref, d2 = x[2] - st_ref, d3 = x[3] - st_ref;
+                                st_s += (d0 + d1) + (d2 + d3);
+                                st_q = fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, fmaf(d3, d3, st_q))));
+                            } else if (round_in > 0) {
+                                const int left_in_share = round_in - 4 * lane;  // samples of this vector inside
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                const float dl = k < left_in_share ? x[k] - st_ref : 0.f;
-                                st_s += dl;
-                                st_q = fmaf(dl, dl, st_q);
+                                for (int k = 0; k < 4; ++k) {
+                                    const float dl = k < left_in_share ? x[k] - st_ref : 0.f;
+                                    st_s += dl;
+                                    st_q = fmaf(dl, dl, st_q);
+                                }
                             }
                         }
                     }
@@ -638,8 +645,14 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         }
         if constexpr (RAGGED) {
             if (do_stats) {
-                const float ws = dsp_wave_sum(st_s), wq = dsp_wave_sum(st_q);
-                if (lane == 0) {
+                // sums over each row of 16 lanes with DPP (vector pipe, no LDS traffic), then four lanes add to the
+                // utterance's accumulators
+                float ws = st_s, wq = st_q;
+                ws += dpp_f32<0xB1>(ws);  wq += dpp_f32<0xB1>(wq);     // quad_perm [1,0,3,2]
+                ws += dpp_f32<0x4E>(ws);  wq += dpp_f32<0x4E>(wq);     // quad_perm [2,3,0,1]
+                ws += dpp_f32<0x141>(ws); wq += dpp_f32<0x141>(wq);    // row_half_mirror
+                ws += dpp_f32<0x140>(ws); wq += dpp_f32<0x140>(wq);    // row_mirror
+                if ((lane & 15) == 0) {
                     unsafeAtomicAdd(bg.stats + 2 * utt, (double)ws);
                     unsafeAtomicAdd(bg.stats + 2 * utt + 1, (double)wq);
                 }

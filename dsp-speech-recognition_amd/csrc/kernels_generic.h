@@ -724,8 +724,17 @@ __global__ __launch_bounds__(1024) void endpoint_layout_kernel(const int32_t* __
                                                                double step, double rate, int32_t L, int32_t S,
                                                                const int64_t* __restrict__ jitter,
                                                                int64_t* __restrict__ seg, int64_t* __restrict__ dst_off,
-                                                               int64_t* __restrict__ frame_off) {
+                                                               int64_t* __restrict__ frame_off,
+                                                               // optional (dsp_endpoint_layout_segments_batch): the tables
+                                                               // dsp_mfcc_delta_segments_batch needs, in the same launch
+                                                               int32_t group_shift = 0, int32_t* __restrict__ group_off = nullptr,
+                                                               int32_t* __restrict__ group_utt = nullptr,
+                                                               int64_t* __restrict__ tile_off = nullptr,
+                                                               double* __restrict__ zero_stats = nullptr) {
     __shared__ int64_t part_s[1024], part_f[1024];
+    __shared__ int32_t part_g[1024], part_t[1024];
+    const int64_t rnd_g = ((int64_t)1 << group_shift) - 1, rnd_t = ((int64_t)1 << DT_SHIFT) - 1;
+    int32_t sum_g = 0, sum_t = 0;
     const int tid = threadIdx.x;
     const int per = (n_utt + 1023) / 1024;
     const int lo = tid * per, hi = min(lo + per, n_utt);
@@ -747,29 +756,52 @@ __global__ __launch_bounds__(1024) void endpoint_layout_kernel(const int32_t* __
         seg[2 * b + 1] = r;
         const int64_t n = r - l;
         sum_s += n;
-        sum_f += n <= L ? 1 : 1 + (n - L + S - 1) / S;
+        const int64_t nf = n <= L ? 1 : 1 + (n - L + S - 1) / S;
+        sum_f += nf;
+        sum_g += (int32_t)((nf + rnd_g) >> group_shift);
+        sum_t += (int32_t)((nf + rnd_t) >> DT_SHIFT);
+        if (zero_stats != nullptr) { zero_stats[2 * b] = 0.0; zero_stats[2 * b + 1] = 0.0; }
     }
     part_s[tid] = sum_s;
     part_f[tid] = sum_f;
+    part_g[tid] = sum_g;
+    part_t[tid] = sum_t;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
         const int64_t vs = tid >= off ? part_s[tid - off] : 0, vf = tid >= off ? part_f[tid - off] : 0;
+        const int32_t vg = tid >= off ? part_g[tid - off] : 0, vt = tid >= off ? part_t[tid - off] : 0;
         __syncthreads();
         part_s[tid] += vs;
         part_f[tid] += vf;
+        part_g[tid] += vg;
+        part_t[tid] += vt;
         __syncthreads();
     }
-    int64_t run_s = part_s[tid] - sum_s, run_f = part_f[tid] - sum_f;
+    int64_t run_s = part_s[tid] - sum_s, run_f = part_f[tid] - sum_f, run_t = part_t[tid] - sum_t;
+    int32_t run_g = part_g[tid] - sum_g;
     for (int b = lo; b < hi; ++b) {
         dst_off[b] = run_s;
         frame_off[b] = run_f;
         const int64_t n = seg[2 * b + 1] - seg[2 * b];
+        const int64_t nf = n <= L ? 1 : 1 + (n - L + S - 1) / S;
         run_s += n;
-        run_f += n <= L ? 1 : 1 + (n - L + S - 1) / S;
+        run_f += nf;
+        if (group_off != nullptr) {
+            group_off[b] = run_g;
+            const int32_t ng = (int32_t)((nf + rnd_g) >> group_shift);
+            for (int32_t g = 0; g < ng; ++g) group_utt[run_g + g] = b;
+            run_g += ng;
+        }
+        if (tile_off != nullptr) {
+            tile_off[b] = run_t;
+            run_t += (nf + rnd_t) >> DT_SHIFT;
+        }
     }
     if (tid == 1023) {
         dst_off[n_utt] = part_s[1023];
         frame_off[n_utt] = part_f[1023];
+        if (group_off != nullptr) group_off[n_utt] = part_g[1023];
+        if (tile_off != nullptr) tile_off[n_utt] = part_t[1023];
     }
 }
 

@@ -507,7 +507,7 @@ static int vad_tile_launch_k(const VadParams& P, const BatchGeom& bg, const void
 
 template <int FR>
 static int vad_tile_launch_t(VadParams P, const BatchGeom& bg, const void* d_wave, int dtype, double* d_amp,
-                             int32_t* d_zcr, hipStream_t st) {
+                             int32_t* d_zcr, hipStream_t st, const DspRaggedTables* pre = nullptr) {
     P.span_vec = ((FR - 1) * P.S + P.L + 3) / 4;
     P.wave_floats = (4 * (P.span_vec + 1) + 63) / 64 * 64;
     constexpr int SHIFT = FR == 16 ? 4 : 2;
@@ -519,28 +519,35 @@ static int vad_tile_launch_t(VadParams P, const BatchGeom& bg, const void* d_wav
         return vad_tile_launch_k<DSP_WAVE_F32, FR, false>(P, bg, d_wave, d_amp, d_zcr, P.total_groups, st);
     }
     const int64_t bound = bg.total_frames / FR + bg.n_utt;
-    const size_t ws_bytes = ((size_t)bg.n_utt + 1 + (size_t)bound) * sizeof(int32_t);
-    DspWorkspace* w = dsp_workspace_pool().acquire(ws_bytes, st);
-    if (!w) return DSP_EHIP;
-    int32_t* group_off = static_cast<int32_t*>(w->ptr);
-    int32_t* group_utt = group_off + bg.n_utt + 1;
-    f512_build_group_tables(bg.frame_off, bg.n_utt, SHIFT, group_off, group_utt, st);
-    P.group_off = group_off;
-    P.group_utt = group_utt;
+    DspWorkspace* w = nullptr;
+    if (pre != nullptr && pre->shift == SHIFT) {   // tables of a dsp_layout: built once per batch shape
+        P.group_off = pre->group_off;
+        P.group_utt = pre->group_utt;
+    } else {
+        const size_t ws_bytes = ((size_t)bg.n_utt + 1 + (size_t)bound) * sizeof(int32_t);
+        w = dsp_workspace_pool().acquire(ws_bytes, st);
+        if (!w) return DSP_EHIP;
+        int32_t* group_off = static_cast<int32_t*>(w->ptr);
+        int32_t* group_utt = group_off + bg.n_utt + 1;
+        f512_build_group_tables(bg.frame_off, bg.n_utt, SHIFT, group_off, group_utt, st);
+        P.group_off = group_off;
+        P.group_utt = group_utt;
+    }
     int rc;
     if (dtype == DSP_WAVE_I16)
         rc = vad_tile_launch_k<DSP_WAVE_I16, FR, true>(P, bg, d_wave, d_amp, d_zcr, bound, st);
     else
         rc = vad_tile_launch_k<DSP_WAVE_F32, FR, true>(P, bg, d_wave, d_amp, d_zcr, bound, st);
-    if (dsp_workspace_pool().release(w, st) != 0 && rc == DSP_OK) rc = DSP_EHIP;
+    if (w != nullptr && dsp_workspace_pool().release(w, st) != 0 && rc == DSP_OK) rc = DSP_EHIP;
     return rc;
 }
 
 static inline int vad_tile_launch(int FR, int32_t L, int32_t S, int32_t use_sq, const BatchGeom& bg, const void* d_wave,
-                                  int dtype, double* d_amp, int32_t* d_zcr, hipStream_t st) {
+                                  int dtype, double* d_amp, int32_t* d_zcr, hipStream_t st,
+                                  const DspRaggedTables* pre = nullptr) {
     VadParams P;
     memset(&P, 0, sizeof(P));
     P.L = L; P.S = S; P.use_sq = use_sq;
-    if (FR == 16) return vad_tile_launch_t<16>(P, bg, d_wave, dtype, d_amp, d_zcr, st);
-    return vad_tile_launch_t<4>(P, bg, d_wave, dtype, d_amp, d_zcr, st);
+    if (FR == 16) return vad_tile_launch_t<16>(P, bg, d_wave, dtype, d_amp, d_zcr, st, pre);
+    return vad_tile_launch_t<4>(P, bg, d_wave, dtype, d_amp, d_zcr, st, pre);
 }

@@ -64,6 +64,11 @@ SIGNATURES = {
     'dsp_segments_workspace_bytes': (C.c_int, [c_vp, c_i32, c_i64, C.POINTER(C.c_size_t)]),
     'dsp_mfcc_delta_segments_batch': (C.c_int, [c_vp, c_vp, C.c_int, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32,
                                                 c_vp, C.c_size_t, c_vp, c_vp]),
+    'dsp_endpoint_layout_segments_batch': (C.c_int, [c_vp, c_vp, c_i32, c_f64, c_f64, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                                     c_i64, c_vp, C.c_size_t, c_vp]),
+    'dsp_layout_create': (C.c_int, [c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, C.POINTER(c_vp)]),
+    'dsp_layout_destroy': (C.c_int, [c_vp]),
+    'dsp_vad_features_layout_batch': (C.c_int, [c_vp, c_vp, C.c_int, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     'dsp_trim_scale_batch': (C.c_int, [c_vp, C.c_int, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     'dsp_endpoint_rule_batch': (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_f64, c_f64, c_vp, c_vp]),
     'dsp_endpoint_layout_batch': (C.c_int, [c_vp, c_vp, c_i32, c_f64, c_f64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),

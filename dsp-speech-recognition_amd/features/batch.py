@@ -72,6 +72,34 @@ class _BatchLayout:
     def p_frame(self):
         return self.d_frame.ptr if self.d_frame is not None else None
 
+    def vad_handle(self, L, S):
+        """dsp_layout of this (ragged, long-lived) layout for (L, S) framing: the VAD kernel's index tables, built once
+        instead of on every call (include/dsp_frontend.h: dsp_layout_create).  None for dense or scratch layouts."""
+        if self.uniform_samples > 0 or not isinstance(self.d_frame, nat.DeviceBuffer):
+            return None
+        h = getattr(self, '_vad_handle', None)
+        if h is None:
+            import ctypes as C
+            out = C.c_void_p(0)
+            nat.check(nat.load().dsp_layout_create(self.d_frame.ptr, self.n_utt, self.total_frames, int(L), int(S), None,
+                                                   C.byref(out)))
+            nat.check(nat.load().dsp_stream_synchronize(None))
+            h = self._vad_handle = _LayoutHandle(out.value)
+        return h.handle
+
+
+class _LayoutHandle:
+    def __init__(self, handle):
+        self.handle = handle
+
+    def __del__(self):
+        if self.handle:
+            try:
+                nat.load().dsp_layout_destroy(self.handle)
+            except Exception:
+                pass
+            self.handle = None
+
 
 def _layout_for(L, S, waves, sample_offsets):
     shape = tuple(waves.shape)
@@ -169,9 +197,14 @@ class EndpointPlan:
     def run_raw(self, d_wave, wave_dtype, layout, d_amp_sum, d_zcr, d_endpoints, stream=None):
         lib = nat.load()
         st = _stream_ptr(stream)
-        nat.check(lib.dsp_vad_features_batch(d_wave, wave_dtype, layout.p_sample, layout.p_frame,
-                                             layout.n_utt, layout.total_frames, layout.uniform_samples,
-                                             self.L, self.S, 0, d_amp_sum, d_zcr, st))
+        handle = layout.vad_handle(self.L, self.S) if hasattr(layout, 'vad_handle') else None
+        if handle is not None:      # long-lived ragged layout: its index tables were built once
+            nat.check(lib.dsp_vad_features_layout_batch(handle, d_wave, wave_dtype, layout.p_sample, layout.p_frame, 0,
+                                                        d_amp_sum, d_zcr, st))
+        else:
+            nat.check(lib.dsp_vad_features_batch(d_wave, wave_dtype, layout.p_sample, layout.p_frame,
+                                                 layout.n_utt, layout.total_frames, layout.uniform_samples,
+                                                 self.L, self.S, 0, d_amp_sum, d_zcr, st))
         if layout.d_frame is None:  # the rule kernel always takes explicit frame offsets
             layout.d_frame = nat.DeviceBuffer(layout.frame_offsets.nbytes).upload(layout.frame_offsets)
         nat.check(lib.dsp_endpoint_rule_batch(d_amp_sum, d_zcr, layout.d_frame.ptr, layout.n_utt, self.L,

@@ -151,15 +151,22 @@ class VadMfccPipeline:
         st = _stream_ptr(stream)
         ep, fp = self.endpoint, self.features
         ep.run_raw(d_wave, wave_dtype, lay.vad, lay.d_amp.ptr, lay.d_zcr.ptr, lay.d_ep.ptr, st)
-        nat.check(lib.dsp_endpoint_layout_batch(lay.d_ep.ptr, lay.vad.p_sample, lay.n_utt, float(ep.step),
-                                                float(ep.rate), fp.L, fp.S, d_jitter, lay.d_seg.ptr,
-                                                lay.d_dst_off.ptr, lay.d_frame_off.ptr, st))
-        if lay.d_work is not None and not self.copy_trimmed:
+        in_place = lay.d_work is not None and not self.copy_trimmed
+        if in_place:      # one launch: segments, offsets AND the tables / zeroed statistics of the in-place feature stage
+            nat.check(lib.dsp_endpoint_layout_segments_batch(lay.d_ep.ptr, lay.vad.p_sample, lay.n_utt, float(ep.step),
+                                                             float(ep.rate), d_jitter, lay.d_seg.ptr, lay.d_dst_off.ptr,
+                                                             lay.d_frame_off.ptr, fp.plan.handle, max(lay.frames_bound, 1),
+                                                             lay.d_work.ptr, lay.d_work.nbytes, st))
+        else:
+            nat.check(lib.dsp_endpoint_layout_batch(lay.d_ep.ptr, lay.vad.p_sample, lay.n_utt, float(ep.step),
+                                                    float(ep.rate), fp.L, fp.S, d_jitter, lay.d_seg.ptr,
+                                                    lay.d_dst_off.ptr, lay.d_frame_off.ptr, st))
+        if in_place:
             # the feature kernel reads sig[left:right] where it lies; unit variance becomes a shift of c0
             rc = lib.dsp_mfcc_delta_segments_batch(fp.plan.handle, d_wave, wave_dtype, lay.vad.p_sample, lay.d_seg.ptr,
                                                    lay.d_frame_off.ptr, lay.n_utt, max(lay.frames_bound, 1), lay.delta_n,
-                                                   1 if self.unit_variance else 0, lay.d_work.ptr, lay.d_work.nbytes,
-                                                   d_out, st)
+                                                   (1 if self.unit_variance else 0) | 2, lay.d_work.ptr,
+                                                   lay.d_work.nbytes, d_out, st)
             if rc == nat.OK:
                 return
             if rc != 1:                      # 1 = "not served in place": take the copy below

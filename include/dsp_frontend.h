@@ -178,6 +178,22 @@ int dsp_endpoint_rule_batch(const double* d_amp_sum, const int32_t* d_zcr,
                             double cfg_frame, double cfg_step, int32_t* d_endpoints, void* stream);
 
 /*
+ * Batch-layout handle: the index tables a ragged call would otherwise build with a small launch of its own (into a
+ * pooled workspace) on EVERY call, built ONCE for a batch shape -- the frame offsets of `frame_len` / `frame_step`
+ * framing of n_utt utterances.  dsp_vad_features_layout_batch is dsp_vad_features_batch with those tables: no table
+ * launch, no pooled workspace, so the call can be captured into a HIP graph.  (The feature stage of configs[3] has
+ * data-dependent offsets -- the trimmed clips -- and keeps its tables in the caller's work buffer instead:
+ * dsp_endpoint_layout_segments_batch.)  The tables are built on `stream`; the handle belongs to the current device.
+ */
+typedef struct dsp_layout dsp_layout;
+int dsp_layout_create(const int64_t* d_frame_offsets, int32_t n_utt, int64_t n_frames_total, int32_t frame_len,
+                      int32_t frame_step, void* stream, dsp_layout** out);
+int dsp_layout_destroy(dsp_layout* layout);
+int dsp_vad_features_layout_batch(const dsp_layout* layout, const void* d_wave, int wave_dtype,
+                                  const int64_t* d_sample_offsets, const int64_t* d_frame_offsets, int32_t use_sq,
+                                  double* d_amp_sum, int32_t* d_zcr, void* stream);
+
+/*
  * Endpoint-trimmed copy (fp32 out): utterance b keeps samples [segments[2b], segments[2b+1]) relative
  * to its start and lands at d_dst_offsets[b]; with unit_variance != 0 it is divided by its population
  * standard deviation (zero -> 1), i.e. sig[left:right] -> sklearn scale(with_mean=False) as
@@ -201,12 +217,23 @@ int dsp_trim_scale_batch(const void* d_wave, int wave_dtype, const int64_t* d_sa
  * Returns 1 (not an error) when the plan / buffer is not served in place (no NFFT = 512 fast path, misaligned buffer,
  * unit variance without appendEnergy): use dsp_trim_scale_batch + dsp_mfcc_delta_batch then.
  */
+#define DSP_SEG_UNIT_VARIANCE 1   /* flags: the clips count as divided by their standard deviation (see above) */
+#define DSP_SEG_TABLES_READY 2    /* flags: d_work already holds the tables (dsp_endpoint_layout_segments_batch) */
 int dsp_segments_workspace_bytes(const dsp_plan* plan, int32_t n_utt, int64_t n_frames_bound, size_t* bytes);
 int dsp_mfcc_delta_segments_batch(const dsp_plan* plan, const void* d_wave, int wave_dtype,
                                   const int64_t* d_sample_offsets, const int64_t* d_segments,
                                   const int64_t* d_frame_offsets, int32_t n_utt, int64_t n_frames_bound,
-                                  int32_t delta_n, int32_t unit_variance, void* d_work, size_t work_bytes,
+                                  int32_t delta_n, int32_t flags, void* d_work, size_t work_bytes,
                                   float* d_out, void* stream);
+/*
+ * dsp_endpoint_layout_batch (below) for `plan`'s framing that ALSO leaves, in the same launch, everything
+ * dsp_mfcc_delta_segments_batch would otherwise build with a launch of its own (frame-group and delta-tile tables of the
+ * trimmed clips, zeroed statistics) in d_work: pass DSP_SEG_TABLES_READY to that call then.
+ */
+int dsp_endpoint_layout_segments_batch(const int32_t* d_endpoints, const int64_t* d_sample_offsets, int32_t n_utt,
+                                       double cfg_step, double rate, const int64_t* d_jitter, int64_t* d_segments,
+                                       int64_t* d_dst_offsets, int64_t* d_frame_offsets, const dsp_plan* plan,
+                                       int64_t n_frames_bound, void* d_work, size_t work_bytes, void* stream);
 
 /*
  * Device-side glue between dsp_endpoint_rule_batch and dsp_trim_scale_batch / dsp_features_batch, so that

@@ -266,6 +266,45 @@ def test_dense_step_is_hip_graph_capturable():
         assert torch.equal(out, eager)
 
 
+def test_vad_pipeline_is_hip_graph_capturable_and_replays_on_new_data():
+    """configs[3] end to end as ONE graph: with the batch-layout handle (VAD index tables built once), the tables
+    of the trimmed clips written by the layout kernel into the caller's work buffer, and the in-place feature stage,
+    VadMfccPipeline.launch allocates nothing, leases no pooled workspace and never synchronises -- so it can be
+    captured, and replayed after the INPUT BUFFER has been overwritten with other clips of the same lengths
+    (different endpoints, different frame counts: every data-dependent table is rebuilt on the device)."""
+    import torch
+    from features import _native as nat
+    from features.pipeline import VadMfccPipeline
+    from golden_cases import make_signal
+    dev = torch.device('cuda', 0)
+    lens = [16000 + 1700 * i for i in range(8)]
+    a = [make_signal(('vad', 400 + i, n)) for i, n in enumerate(lens)]
+    b = [make_signal(('vad', 500 + i, n)) for i, n in enumerate(lens)]
+    so = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    pipe = VadMfccPipeline(rate=16000, unit_variance=True, winfunc=np.hamming, **{k: v for k, v in CFG.items() if k != 'samplerate'})
+    want_a = pipe.run(np.concatenate(a), so, delta_n=2)
+    want_b = pipe.run(np.concatenate(b), so, delta_n=2)
+    assert not np.array_equal(want_a[2], want_b[2])                      # the two batches trim differently
+    lay = pipe.prepare(so, 2)
+    buf = torch.from_numpy(np.concatenate(a)).to(dev)
+    out = torch.zeros((lay.frames_bound, lay.D), device=dev)
+    pipe.launch(buf.data_ptr(), nat.WAVE_I16, lay, out.data_ptr(), torch.cuda.current_stream(dev))   # eager warm-up
+    torch.cuda.synchronize(dev)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(dev)
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            pipe.launch(buf.data_ptr(), nat.WAVE_I16, lay, out.data_ptr(), torch.cuda.current_stream(dev))
+    for clips, want in ((b, want_b), (a, want_a), (b, want_b)):
+        buf.copy_(torch.from_numpy(np.concatenate(clips)))
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize(dev)
+        fo = lay.d_frame_off.download((len(lens) + 1,), np.int64)
+        assert np.array_equal(fo, want[1])
+        assert np.array_equal(out[:fo[-1]].cpu().numpy(), want[0])
+
+
 def test_model_feature_batch_training_path_with_jitter(golden):
     """model.py:144 calls get_batch_full(augment=True): the endpoint jitter of model.py:54-60, batched on
     the device (host-drawn offsets -> dsp_endpoint_layout_batch), against outputs of the REAL reference run

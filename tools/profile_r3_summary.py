@@ -17,8 +17,8 @@ def short(name):
     m = re.search(r'mfcc512_kernel<([^>]*)>', name)
     if m:   # the last template argument is the fused-delta window (0: the MFCC-only kernel)
         args = [a.strip() for a in m.group(1).split(',')]
-        fd = args[8] if len(args) > 8 else '0'
-        ragged = args[7] == 'true' if len(args) > 7 else False
+        fd = args[7] if len(args) > 7 else '0'      # <NROWS, NI, CAPS, NSTAGE, DTYPE, WAVES, RAGGED, FD>
+        ragged = len(args) > 6 and args[6] in ('true', '1')
         return 'mfcc512_fused' if fd not in ('0', 'false') else ('mfcc512_ragged' if ragged else 'mfcc512_kernel')
     for key in ('mfcc1536_kernel', 'delta_rows_kernel', 'delta_tiled_kernel', 'vad_sum_kernel',
                 'vad_vec_kernel', 'endpoint_rule_kernel', 'endpoint_layout_kernel', 'trim_scale_kernel',
