@@ -711,7 +711,7 @@ int dsp_trim_scale_batch(const void* d_wave, int wave_dtype, const int64_t* d_sa
 
 namespace {
 struct SegWork {
-    size_t stats, tile, goff, gutt, cep, total;
+    size_t stats, tile, goff, gutt, tutt, cep, total;
 };
 // layout of the caller-owned work buffer of dsp_mfcc_delta_segments_batch (every part 256-byte aligned)
 SegWork seg_work_layout(int32_t n_utt, int64_t n_frames_bound, int32_t C) {
@@ -721,7 +721,8 @@ SegWork seg_work_layout(int32_t n_utt, int64_t n_frames_bound, int32_t C) {
     w.tile = w.stats + pad((size_t)n_utt * 2 * sizeof(double));
     w.goff = w.tile + pad(((size_t)n_utt + 1) * sizeof(int64_t));
     w.gutt = w.goff + pad(((size_t)n_utt + 1) * sizeof(int32_t));
-    w.cep = w.gutt + pad(((size_t)(n_frames_bound >> 3) + (size_t)n_utt) * sizeof(int32_t));
+    w.tutt = w.gutt + pad(((size_t)(n_frames_bound >> 3) + (size_t)n_utt) * sizeof(int32_t));
+    w.cep = w.tutt + pad(((size_t)(n_frames_bound >> DT_SHIFT) + (size_t)n_utt) * sizeof(int32_t));
     w.total = w.cep + pad((size_t)n_frames_bound * (size_t)C * sizeof(float));
     return w;
 }
@@ -785,10 +786,12 @@ int dsp_mfcc_delta_segments_batch(const dsp_plan* plan, const void* d_wave, int 
     const float inv_den = (float)(1.0 / (2.0 * den));
     const int64_t blocks = n_frames_bound / DT_TILE + n_utt;
     if (blocks > 0x7fffffff) return fail(DSP_EINVAL, "too many delta tiles");
+    // (the tile -> utterance table exists only when the layout kernel built the tables)
+    const int32_t* tile_utt = (flags & DSP_SEG_TABLES_READY) ? reinterpret_cast<const int32_t*>(wp + w.tutt) : nullptr;
     if (C == 13)
-        delta_rows_kernel<13><<<(int)blocks, 256, lds, st>>>(cep, dg, C, delta_n, inv_den, d_out, 0, tile_off, d_segments, stats);
+        delta_rows_kernel<13><<<(int)blocks, 256, lds, st>>>(cep, dg, C, delta_n, inv_den, d_out, 0, tile_off, d_segments, stats, tile_utt);
     else
-        delta_rows_kernel<0><<<(int)blocks, 256, lds, st>>>(cep, dg, C, delta_n, inv_den, d_out, 0, tile_off, d_segments, stats);
+        delta_rows_kernel<0><<<(int)blocks, 256, lds, st>>>(cep, dg, C, delta_n, inv_den, d_out, 0, tile_off, d_segments, stats, tile_utt);
     HIP_TRY(hipGetLastError());
     return DSP_OK;
 }
@@ -822,7 +825,8 @@ int dsp_endpoint_layout_segments_batch(const int32_t* d_endpoints, const int64_t
     endpoint_layout_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(
         d_endpoints, d_sample_offsets, n_utt, cfg_step, rate, plan->L, plan->S, d_jitter, d_segments, d_dst_offsets,
         d_frame_offsets, 3, reinterpret_cast<int32_t*>(wp + w.goff), reinterpret_cast<int32_t*>(wp + w.gutt),
-        reinterpret_cast<int64_t*>(wp + w.tile), reinterpret_cast<double*>(wp + w.stats));
+        reinterpret_cast<int64_t*>(wp + w.tile), reinterpret_cast<double*>(wp + w.stats),
+        reinterpret_cast<int32_t*>(wp + w.tutt));
     HIP_TRY(hipGetLastError());
     return DSP_OK;
 }

@@ -40,7 +40,7 @@
 struct F512Params {
     const float* tables;   // device blob copied to LDS by every workgroup
     int32_t tab_floats;    // multiple of 64 floats (256 B)
-    int32_t off_tw1, off_dct, off_melw, off_mels, off_bias;
+    int32_t off_tw1, off_dct, off_melw, off_mels, off_bias, off_coop;
     int32_t melw_row;      // floats per lane row of mel weights (multiple of 4, /4 odd: conflict-free b128)
     int32_t L, S, M, C, append_energy;
     float preemph;
@@ -452,6 +452,19 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         int lane = tid & 63;
         asm volatile("" : "+v"(lane));
         const int f = lane >> 3, c = lane & 7;
+        // (F512_COOP, an experiment that is NOT compiled into the product library: rows 0 and 16 by two FFT8 across the
+        //  frame's lanes instead of lane 0's packed FFT16.  Measured on the MI355X: 6 % fewer vector instructions per
+        //  group (1330 instead of 1420), parity green -- and no gain in time at any batch size (39.4 vs 40.2 us at
+        //  configs[1], 414 vs 418 us at 12 500 utterances): the 21 extra DPP operands with their wait states and the
+        //  serial butterfly chain cost what the idle lanes did.  Kept as a build flag for the record.)
+#ifdef F512_COOP
+        // Column pair of this lane in pass 1: 0, 1, 2, 3, 7, 6, 5, 4 -- chosen so that the three stages of a
+        // decimation-in-frequency FFT8 ACROSS the frame's lanes (rows 0 and 16, below) pair lane c with c ^ 7, c ^ 2
+        // and c ^ 1: row_half_mirror and two quad_perms, one DPP operand each.
+        const int np = c < 4 ? c : 11 - c;
+#else
+        const int np = c;
+#endif
         float v0 = 0.f, v1 = 0.f;   // the frame's two cepstral coefficients this lane ends up with
         do {
         if constexpr (FD) { if (r >= run.n_groups) break; }
@@ -664,14 +677,14 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         // ---- pass 1: window, complex FFT32 over n1 of (column 2c) + i (column 2c+1) ----
         cpx z[32];
         {
-            const float* frp = wbuf + d + f * P.S + 2 * c + ((!RAGGED && f >= grp.nf1) ? P.seam_off : 0);
+            const float* frp = wbuf + d + f * P.S + 2 * np + ((!RAGGED && f >= grp.nf1) ? P.seam_off : 0);
             const uint32_t fr = f512_lds_addr(frp);
-            const uint32_t wn = f512_lds_addr(s_win + 2 * c);
+            const uint32_t wn = f512_lds_addr(s_win + 2 * np);
             if (RAGGED && (d & 1)) {
                 // odd offset inside the aligned LDS image: the column pair is not 8-byte aligned
 #pragma unroll
                 for (int n1 = 0; n1 < NROWS; ++n1) {
-                    const float2 wv = *reinterpret_cast<const float2*>(s_win + 2 * c + 16 * n1);
+                    const float2 wv = *reinterpret_cast<const float2*>(s_win + 2 * np + 16 * n1);
                     z[n1] = {frp[16 * n1] * wv.x, frp[16 * n1 + 1] * wv.y};
                 }
             } else {
@@ -686,6 +699,67 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         F512_STAMP(2);
         F512_PIN(z);
 
+#ifdef F512_COOP
+        // ---- rows 0 and 16 of the column transforms are real (z[0] = plain, z[16] = alternating column sums): their
+        //      transforms over n2 are the 17 bins X[16 j].  Instead of packing them into one lane's FFT16 and finishing
+        //      in that lane alone (1 lane in 8 busy for ~170 instructions), the frame's 8 lanes run two complex FFT8
+        //      ACROSS lanes (DPP butterflies) and each lane ends with one even and one odd bin:
+        //        X[32 k]      = F[k],  F = real FFT16 of the row-0 values   (y_n = a[2n] + i a[2n+1], FFT8, untangle with k <-> 8 - k)
+        //        X[16 + 32 k] = O[k],  O[k] = sum_m b[m] W32^(m (2k+1))     (w_n = (b[2n] + i b[2n+1]) W16^n, FFT8, untangle with k <-> 7 - k)
+        //      Both untangles have the form |s + t|^2 with s = A_k + conj(A_partner), t = W' (A_k - conj(A_partner)); the
+        //      values carry the same factor 2 as the other rows. ----
+        float coop_e, coop_o, coop_e8;
+        int coop_k;
+        {
+            const float4* ct = reinterpret_cast<const float4*>(smem + P.off_coop + 16 * c);
+            const float4 c0 = ct[0], c1 = ct[1], c2 = ct[2], c3 = ct[3];
+            // c0 = (sign1, sign2, sign3, -), c1 = (tw1, tw2), c2 = (W16^n, -i W16^k), c3 = (-i W32^(2k+1), k as int, -)
+            cpx y = z[0];
+            cpx w = cmulc(z[16], c2.x, c2.y);
+            // stage 1: partner c ^ 7
+            {
+                const cpx ty = {dpp_f32<0x141>(y.x), dpp_f32<0x141>(y.y)}, tw = {dpp_f32<0x141>(w.x), dpp_f32<0x141>(w.y)};
+                y = cmulc({fmaf(y.x, c0.x, ty.x), fmaf(y.y, c0.x, ty.y)}, c1.x, c1.y);
+                w = cmulc({fmaf(w.x, c0.x, tw.x), fmaf(w.y, c0.x, tw.y)}, c1.x, c1.y);
+            }
+            // stage 2: partner c ^ 2
+            {
+                const cpx ty = {dpp_f32<0x4E>(y.x), dpp_f32<0x4E>(y.y)}, tw = {dpp_f32<0x4E>(w.x), dpp_f32<0x4E>(w.y)};
+                y = cmulc({fmaf(y.x, c0.y, ty.x), fmaf(y.y, c0.y, ty.y)}, c1.z, c1.w);
+                w = cmulc({fmaf(w.x, c0.y, tw.x), fmaf(w.y, c0.y, tw.y)}, c1.z, c1.w);
+            }
+            // stage 3: partner c ^ 1
+            {
+                const cpx ty = {dpp_f32<0xB1>(y.x), dpp_f32<0xB1>(y.y)}, tw = {dpp_f32<0xB1>(w.x), dpp_f32<0xB1>(w.y)};
+                y = {fmaf(y.x, c0.z, ty.x), fmaf(y.y, c0.z, ty.y)};
+                w = {fmaf(w.x, c0.z, tw.x), fmaf(w.y, c0.z, tw.y)};
+            }
+            // lane c now holds output k(c) of both transforms: k = 0, 4, 2, 6, 7, 3, 5, 1.
+            // even bins: partner output (8 - k) mod 8 sits in lane {0, 1, 3, 2 | 7, 6, 5, 4}[c]
+            cpx py, pw;
+            {
+                int r0 = __builtin_amdgcn_update_dpp(0, __float_as_int(y.x), 0xB4, 0xF, 0x5, false);      // quad_perm [0,1,3,2], quads 0 and 2
+                r0 = __builtin_amdgcn_update_dpp(r0, __float_as_int(y.x), 0x1B, 0xF, 0xA, false);         // quad_perm [3,2,1,0], quads 1 and 3
+                int r1 = __builtin_amdgcn_update_dpp(0, __float_as_int(y.y), 0xB4, 0xF, 0x5, false);
+                r1 = __builtin_amdgcn_update_dpp(r1, __float_as_int(y.y), 0x1B, 0xF, 0xA, false);
+                py = {__int_as_float(r0), __int_as_float(r1)};
+                // odd bins: partner output 7 - k sits in lane c ^ 4 = (c ^ 7) ^ 3
+                pw = {dpp_f32<0x1B>(dpp_f32<0x141>(w.x)), dpp_f32<0x1B>(dpp_f32<0x141>(w.y))};
+            }
+            {
+                const cpx sE = {y.x + py.x, y.y - py.y}, dE = {y.x - py.x, y.y + py.y};
+                const cpx tE = cmulc(dE, c2.z, c2.w);
+                const cpx ep = {sE.x + tE.x, sE.y + tE.y}, em = {sE.x - tE.x, sE.y - tE.y};
+                coop_e = fmaf(ep.x, ep.x, ep.y * ep.y);
+                coop_e8 = fmaf(em.x, em.x, em.y * em.y);
+                const cpx sO = {w.x + pw.x, w.y - pw.y}, dO = {w.x - pw.x, w.y + pw.y};
+                const cpx tO = cmulc(dO, c3.x, c3.y);
+                const cpx op = {sO.x + tO.x, sO.y + tO.y};
+                coop_o = fmaf(op.x, op.x, op.y * op.y);
+            }
+            coop_k = __float_as_int(c3.z);
+        }
+#endif
         // untangle the two real columns (rows k1 = 0..16, factor 2 kept) and twiddle by W512^(n2 k1)
         cpx ra[16], rb[16];  // index k1 = 1..15 used
 #pragma unroll
@@ -697,7 +771,9 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
             ra[k1] = cmulc(a, t.x, t.y);
             rb[k1] = cmulc(b, t.z, t.w);
         }
+#ifndef F512_COOP
         const float qa = 2.f * z[0].x, qb = 2.f * z[0].y, pa = 2.f * z[16].x, pb = 2.f * z[16].y;
+#endif
 
         F512_PIN(ra); F512_PIN(rb);
         F512_STAMP(3);
@@ -706,13 +782,17 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         float* xb = wbuf + f * 256;
         cpx u0[16], u1[16];
         {
+#ifndef F512_COOP
             const int s0x = sigma_hi;  // unit 0: (0 >> 1) ^ sigma_hi
             *reinterpret_cast<float2*>(xb + 4 * ((c >> 1) ^ s0x) + 2 * (c & 1)) = make_float2(qa + pa, qb + pb);
             *reinterpret_cast<float2*>(xb + 4 * ((4 + (c >> 1)) ^ s0x) + 2 * (c & 1)) = make_float2(qa - pa, qb - pb);
+#endif
+            // (slot 0 of lane 0 -- "row 0" -- is not written with the cooperative unit: that FFT16 runs on whatever the
+            //  buffer holds and its outputs are overwritten / left out below)
 #pragma unroll
             for (int k1 = 1; k1 < 8; ++k1) {
                 const int sg = (k1 >> 1) ^ sigma_hi;
-                *reinterpret_cast<float4*>(xb + k1 * 32 + 4 * (c ^ sg)) = make_float4(ra[k1].x, ra[k1].y, rb[k1].x, rb[k1].y);
+                *reinterpret_cast<float4*>(xb + k1 * 32 + 4 * (np ^ sg)) = make_float4(ra[k1].x, ra[k1].y, rb[k1].x, rb[k1].y);
             }
             F512_FENCE();
             const int sg = (c >> 1) ^ sigma_hi;
@@ -728,7 +808,7 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
             for (int k1 = 8; k1 < 16; ++k1) {
                 const int u = k1 - 8;
                 const int sw = (u >> 1) ^ sigma_hi;
-                *reinterpret_cast<float4*>(xb + u * 32 + 4 * (c ^ sw)) = make_float4(ra[k1].x, ra[k1].y, rb[k1].x, rb[k1].y);
+                *reinterpret_cast<float4*>(xb + u * 32 + 4 * (np ^ sw)) = make_float4(ra[k1].x, ra[k1].y, rb[k1].x, rb[k1].y);
             }
             F512_FENCE();
 #pragma unroll
@@ -753,12 +833,25 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         // power spectrum |X|^2 / 512: rows carry a factor 2 -> 1/2048.  That power of two is applied
         // (exactly) to the mel weights at plan time and to the energy sum once, not to every bin.
         float p0[16], p1[16];
-        constexpr float S1 = 1.0f / 2048.0f, S2 = 1.0f / 16.0f;   // S2: the packed unit carries 8, not 2
+        constexpr float S1 = 1.0f / 2048.0f;
+#ifndef F512_COOP
+        constexpr float S2 = 1.0f / 16.0f;   // the packed unit carries 8, not 2
+#endif
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             p0[k] = fmaf(u0[k].x, u0[k].x, u0[k].y * u0[k].y);
             p1[k] = fmaf(u1[k].x, u1[k].x, u1[k].y * u1[k].y);
         }
+#ifdef F512_COOP
+        // Slot layout of p0 (unit 0): p0[k] -> bin c + 32 k (k < 8), bin 512 - 32 k - c (k >= 8).  Lane 0's slot 0 is the
+        // unused "row 0": its values are garbage, the 9 bins 32 k they land on are overwritten by the cooperative unit
+        // below, and they stay out of the energy.
+        float e0 = p0[0], e1 = p1[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) { e0 += p0[k]; e1 += p1[k]; }
+        e0 = c == 0 ? coop_e8 : e0;                      // lane 0: bin 256 instead
+        e0 += coop_e + coop_o;
+#else
         // Slot layout of p0 (unit 0): p0[k] -> bin c + 32 k (k < 8), bin 512 - 32 k - c (k >= 8).
         // Lane 0 (c = 0) owns bins 16 j instead: the even ones (32 k) fit the same slots, bin 256 is
         // slot 8, slots 9..15 repeat bins 224..32, and the 8 odd ones (16, 48, .., 240) go to podd[].
@@ -800,13 +893,14 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
                 podd[k] = R[2 * k + 1];
             }
         }
+#endif
         // |X|^2 / 512 with the factor 2 of the rows = 1 / 2048; the mel weights and this sum both carry an extra
         // 2^32 (removed again after the logarithm), so that v_log_f32 never sees a denormal
         float energy = (S1 * 4294967296.0f) * frame_allreduce(e0 + e1);
 
-        F512_PIN(p0); F512_PIN(p1); F512_PIN(podd);
+        F512_PIN(p0); F512_PIN(p1);
         F512_STAMP(6);
-        F512_PIN(p0); F512_PIN(p1); F512_PIN(podd);
+        F512_PIN(p0); F512_PIN(p1);
         // ---- power spectrum -> LDS row of this frame: two base registers, immediate offsets ----
         float* ps = wbuf + f * F512_PS_STRIDE;
         {
@@ -819,14 +913,21 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
                 lo[32 * k + 8] = p1[k];
                 hi[32 * (7 - k) - 8] = p1[8 + k];
             }
+#ifdef F512_COOP
+            F512_FENCE();                                // after lane 0's garbage slot: the bins 32 k are rewritten here
+            ps[32 * coop_k] = coop_e;                    // X[32 k]
+            ps[32 * coop_k + 16] = coop_o;               // X[16 + 32 k]
+            // bin 256 from lane 0; the other lanes clear the row padding 257..263 (zero-weight mel taps may read it, so
+            // it must hold finite values; nothing else ever writes these slots in the last frame's row)
+            ps[256 + c] = c == 0 ? coop_e8 : 0.f;
+#else
             if (c == 0) {
 #pragma unroll
                 for (int m = 0; m < 8; ++m) ps[32 * m + 16] = podd[m];
             } else {
-                // row padding 257..263: zero-weight mel taps may read it, so it must hold finite values
-                // (nothing else ever writes these slots in the last frame's row)
                 ps[256 + c] = 0.f;
             }
+#endif
         }
         F512_FENCE();
         F512_STAMP(7);
@@ -1196,14 +1297,38 @@ static inline int fast512_plan_init(dsp_plan* p, const dsp_plan_desc* d, const i
     }
     std::vector<float> win(512, 0.f);
     for (int n = 0; n < L; ++n) win[n] = d->h_window[n];
+#ifdef F512_COOP
+    auto col_pair = [](int c) { return c < 4 ? c : 11 - c; };   // pass-1 column pair of lane c (see the kernel)
+#else
+    auto col_pair = [](int c) { return c; };
+#endif
     std::vector<float> tw1(15 * 8 * 4);
     for (int k1 = 1; k1 < 16; ++k1)
         for (int c = 0; c < 8; ++c)
             for (int h = 0; h < 2; ++h) {
-                const double a = -2.0 * M_PI * (double)((2 * c + h) * k1) / 512.0;
+                const double a = -2.0 * M_PI * (double)((2 * col_pair(c) + h) * k1) / 512.0;
                 tw1[((k1 - 1) * 8 + c) * 4 + 2 * h] = (float)cos(a);
                 tw1[((k1 - 1) * 8 + c) * 4 + 2 * h + 1] = (float)sin(a);
             }
+    // constants of the cross-lane FFT8s of rows 0 and 16, 16 floats per lane (layout: see the kernel)
+    std::vector<float> coop(8 * 16, 0.f);
+    for (int c = 0; c < 8; ++c) {
+        const int n = col_pair(c), n2 = n >> 2, n1 = (n >> 1) & 1, n0 = n & 1;
+        const int k = n0 * 4 + n1 * 2 + n2;                       // DIF: element n ends as output bit-reverse(n)
+        float* t = &coop[(size_t)c * 16];
+        t[0] = n2 ? -1.f : 1.f;
+        t[1] = n1 ? -1.f : 1.f;
+        t[2] = n0 ? -1.f : 1.f;
+        const double a1 = 2.0 * M_PI * (double)(n & 3) / 8.0, a2 = 2.0 * M_PI * (double)n0 / 4.0;
+        t[4] = n2 ? (float)cos(a1) : 1.f;  t[5] = n2 ? (float)-sin(a1) : 0.f;     // W8^(n & 3) on the upper half
+        t[6] = n1 ? (float)cos(a2) : 1.f;  t[7] = n1 ? (float)-sin(a2) : 0.f;     // W4^(n & 1)
+        const double ap = 2.0 * M_PI * (double)n / 16.0, ae = 2.0 * M_PI * (double)k / 16.0,
+                     ao = 2.0 * M_PI * (double)(2 * k + 1) / 32.0;
+        t[8] = (float)cos(ap);   t[9] = (float)-sin(ap);                           // W16^n
+        t[10] = (float)-sin(ae); t[11] = (float)-cos(ae);                          // -i W16^k
+        t[12] = (float)-sin(ao); t[13] = (float)-cos(ao);                          // -i W32^(2k+1)
+        memcpy(&t[14], &k, 4);
+    }
     // Filter slots: lane c, iteration i.  Filters are dealt in mirror pairs (j, M - 1 - j): pair p sits in slot
     // (p % 8, p / 8) and its mirror image in slot (7 - p % 8, NI - 1 - p / 8); with an odd NI the middle iteration holds
     // 4 pairs (lanes c and 7 - c).  The middle filter of an odd M fills both slots of its pair (half weight each).
@@ -1294,7 +1419,8 @@ static inline int fast512_plan_init(dsp_plan* p, const dsp_plan_desc* d, const i
     auto pad64 = [](size_t n) { return (n + 63) / 64 * 64; };
     const size_t o_tw1 = 512, o_dct = o_tw1 + tw1.size(), o_melw = pad64(o_dct + dct.size());
     const size_t o_mels = o_melw + melw.size(), o_bias = o_mels + mels.size();
-    const size_t total = pad64(o_bias + bias.size());
+    const size_t o_coop = (o_bias + bias.size() + 3) / 4 * 4;
+    const size_t total = pad64(o_coop + coop.size());
     std::vector<float> blob(total, 0.f);
     memcpy(blob.data(), win.data(), 512 * 4);
     memcpy(blob.data() + o_tw1, tw1.data(), tw1.size() * 4);
@@ -1302,6 +1428,7 @@ static inline int fast512_plan_init(dsp_plan* p, const dsp_plan_desc* d, const i
     memcpy(blob.data() + o_melw, melw.data(), melw.size() * 4);
     memcpy(blob.data() + o_mels, mels.data(), mels.size() * 4);
     memcpy(blob.data() + o_bias, bias.data(), bias.size() * 4);
+    memcpy(blob.data() + o_coop, coop.data(), coop.size() * 4);
     if (hipMalloc(reinterpret_cast<void**>(&fp->d_tables), total * 4) != hipSuccess ||
         hipMemcpy(fp->d_tables, blob.data(), total * 4, hipMemcpyHostToDevice) != hipSuccess) {
         delete fp;
@@ -1311,6 +1438,7 @@ static inline int fast512_plan_init(dsp_plan* p, const dsp_plan_desc* d, const i
     fp->P.tab_floats = (int32_t)total;
     fp->P.off_tw1 = (int32_t)o_tw1; fp->P.off_dct = (int32_t)o_dct;
     fp->P.off_melw = (int32_t)o_melw; fp->P.off_mels = (int32_t)o_mels; fp->P.off_bias = (int32_t)o_bias;
+    fp->P.off_coop = (int32_t)o_coop;
     fp->P.melw_row = melw_row;
     fp->P.L = L; fp->P.S = d->frame_step; fp->P.M = M; fp->P.C = C;
     fp->P.append_energy = d->append_energy ? 1 : 0;

@@ -333,7 +333,8 @@ __global__ __launch_bounds__(256) void delta_rows_kernel(const float* __restrict
                                                          int32_t tiles_per_utt_uniform,
                                                          const int64_t* __restrict__ tile_off,
                                                          const int64_t* __restrict__ seg = nullptr,
-                                                         const double* __restrict__ stats = nullptr) {
+                                                         const double* __restrict__ stats = nullptr,
+                                                         const int32_t* __restrict__ tile_utt = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float smem_d[];
     __shared__ float s_shift;
     const int D = DC > 0 ? DC : D_rt;
@@ -347,7 +348,8 @@ __global__ __launch_bounds__(256) void delta_rows_kernel(const float* __restrict
         T = (int)bg.uniform_frames;
     } else {
         if ((int64_t)blockIdx.x >= tile_off[bg.n_utt]) return;  // grid is sized by an upper bound
-        const int32_t u = dsp_find_utt(tile_off, bg.n_utt, (int64_t)blockIdx.x);
+        // (a table spares the binary search: ten dependent loads are most of this kernel's latency on small tiles)
+        const int32_t u = tile_utt != nullptr ? tile_utt[blockIdx.x] : dsp_find_utt(tile_off, bg.n_utt, (int64_t)blockIdx.x);
         tile = (int32_t)(blockIdx.x - tile_off[u]);
         base = bg.frame_off[u];
         T = (int)(bg.frame_off[u + 1] - base);
@@ -730,9 +732,10 @@ __global__ __launch_bounds__(1024) void endpoint_layout_kernel(const int32_t* __
                                                                int32_t group_shift = 0, int32_t* __restrict__ group_off = nullptr,
                                                                int32_t* __restrict__ group_utt = nullptr,
                                                                int64_t* __restrict__ tile_off = nullptr,
-                                                               double* __restrict__ zero_stats = nullptr) {
-    __shared__ int64_t part_s[1024], part_f[1024];
-    __shared__ int32_t part_g[1024], part_t[1024];
+                                                               double* __restrict__ zero_stats = nullptr,
+                                                               int32_t* __restrict__ tile_utt = nullptr) {
+    __shared__ int64_t part_s[16], part_f[16];
+    __shared__ int32_t part_g[16], part_t[16];
     const int64_t rnd_g = ((int64_t)1 << group_shift) - 1, rnd_t = ((int64_t)1 << DT_SHIFT) - 1;
     int32_t sum_g = 0, sum_t = 0;
     const int tid = threadIdx.x;
@@ -762,23 +765,30 @@ __global__ __launch_bounds__(1024) void endpoint_layout_kernel(const int32_t* __
         sum_t += (int32_t)((nf + rnd_t) >> DT_SHIFT);
         if (zero_stats != nullptr) { zero_stats[2 * b] = 0.0; zero_stats[2 * b + 1] = 0.0; }
     }
-    part_s[tid] = sum_s;
-    part_f[tid] = sum_f;
-    part_g[tid] = sum_g;
-    part_t[tid] = sum_t;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int64_t vs = tid >= off ? part_s[tid - off] : 0, vf = tid >= off ? part_f[tid - off] : 0;
-        const int32_t vg = tid >= off ? part_g[tid - off] : 0, vt = tid >= off ? part_t[tid - off] : 0;
-        __syncthreads();
-        part_s[tid] += vs;
-        part_f[tid] += vf;
-        part_g[tid] += vg;
-        part_t[tid] += vt;
-        __syncthreads();
+    // inclusive scans of the four per-thread sums: inside each wave with shuffles, across the 16 waves through LDS
+    // (two barriers in all; a Hillis-Steele scan over 1024 threads needs twenty)
+    int64_t inc_s = sum_s, inc_f = sum_f;
+    int32_t inc_g = sum_g, inc_t = sum_t;
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int64_t vs = __shfl_up(inc_s, off, 64), vf = __shfl_up(inc_f, off, 64);
+        const int32_t vg = __shfl_up(inc_g, off, 64), vt = __shfl_up(inc_t, off, 64);
+        if (lane >= off) { inc_s += vs; inc_f += vf; inc_g += vg; inc_t += vt; }
     }
-    int64_t run_s = part_s[tid] - sum_s, run_f = part_f[tid] - sum_f, run_t = part_t[tid] - sum_t;
-    int32_t run_g = part_g[tid] - sum_g;
+    if (lane == 63) { part_s[wv] = inc_s; part_f[wv] = inc_f; part_g[wv] = inc_g; part_t[wv] = inc_t; }
+    __syncthreads();
+    int64_t tot_s = 0, tot_f = 0;
+    int32_t tot_g = 0, tot_t = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int64_t as = part_s[k], af = part_f[k];
+        const int32_t ag = part_g[k], at = part_t[k];
+        if (k < wv) { inc_s += as; inc_f += af; inc_g += ag; inc_t += at; }
+        tot_s += as; tot_f += af; tot_g += ag; tot_t += at;
+    }
+    int64_t run_s = inc_s - sum_s, run_f = inc_f - sum_f, run_t = (int64_t)(inc_t - sum_t);
+    int32_t run_g = inc_g - sum_g;
     for (int b = lo; b < hi; ++b) {
         dst_off[b] = run_s;
         frame_off[b] = run_f;
@@ -794,14 +804,17 @@ __global__ __launch_bounds__(1024) void endpoint_layout_kernel(const int32_t* __
         }
         if (tile_off != nullptr) {
             tile_off[b] = run_t;
-            run_t += (nf + rnd_t) >> DT_SHIFT;
+            const int64_t nt = (nf + rnd_t) >> DT_SHIFT;
+            if (tile_utt != nullptr)
+                for (int64_t g = 0; g < nt; ++g) tile_utt[run_t + g] = b;
+            run_t += nt;
         }
     }
     if (tid == 1023) {
-        dst_off[n_utt] = part_s[1023];
-        frame_off[n_utt] = part_f[1023];
-        if (group_off != nullptr) group_off[n_utt] = part_g[1023];
-        if (tile_off != nullptr) tile_off[n_utt] = part_t[1023];
+        dst_off[n_utt] = tot_s;
+        frame_off[n_utt] = tot_f;
+        if (group_off != nullptr) group_off[n_utt] = tot_g;
+        if (tile_off != nullptr) tile_off[n_utt] = (int64_t)tot_t;
     }
 }
 

@@ -19,6 +19,7 @@ def main():
     ap.add_argument('--batch', type=int, default=1024)
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--copy', action='store_true')
+    ap.add_argument('--no-unit-variance', action='store_true')
     args = ap.parse_args()
     from features import _native as nat
     from features.pipeline import VadMfccPipeline
@@ -26,7 +27,7 @@ def main():
     sigs = make_batch(args.batch)
     so = np.concatenate([[0], np.cumsum([len(s) for s in sigs])]).astype(np.int64)
     d_wave = torch.from_numpy(np.concatenate(sigs)).to(dev)
-    pipe = VadMfccPipeline(rate=16000, frame=0.03, step=0.01, unit_variance=True, winfunc=np.hamming, winlen=0.025,
+    pipe = VadMfccPipeline(rate=16000, frame=0.03, step=0.01, unit_variance=not args.no_unit_variance, winfunc=np.hamming, winlen=0.025,
                            winstep=0.01, numcep=13, nfilt=40, nfft=512, preemph=0.97, ceplifter=22, appendEnergy=True)
     pipe.copy_trimmed = args.copy
     lay = pipe.prepare(so, 2)
