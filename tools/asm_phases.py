@@ -8,7 +8,7 @@ import sys
 
 ROOT = __file__.rsplit('/', 2)[0]
 src = sys.argv[1] if len(sys.argv) > 1 else '/tmp/f512_stamps.s'
-want = sys.argv[2] if len(sys.argv) > 2 else 'mfcc512_kernelILi25ELi5ELi1ELi6ELi0ELi8ELb0E'
+want = sys.argv[2] if len(sys.argv) > 2 else 'mfcc512_kernelILi25ELi5ELi1ELi6ELi0ELi8ELb0ELi0E'
 if len(sys.argv) <= 1:
     subprocess.run(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', f'-I{ROOT}/include',
                     '-I.', '-ffp-contract=fast', '-fno-gpu-rdc', '-fno-slp-vectorize', '-DF512_STAMPS', '-S',
@@ -63,3 +63,16 @@ for k in sorted(table):
         tot.update(table[k])
 est = sum(tot[c] * CYC.get(c, 0) for c in cols)
 print(f'{"loop total":14s}' + ' '.join(f'{tot[c]:5d}' for c in cols) + f'  {est:8.0f}')
+if len(sys.argv) > 3:      # JSON copy for profiles/
+    import json
+    arith = ('f32', 'pk', 'trans')
+    out = {'_comment': 'static instruction mix per phase of ' + want + ' (diagnostic -DF512_STAMPS build: the s_memtime pairs mark '
+                       'the phase boundaries; the staging phase lists all three of its paths, of which a group executes one; '
+                       'the pins of that build add register moves the product build does not have). Wave instructions per '
+                       '8-frame group; arithmetic = f32 + packed + transcendental, the rest of the vector work is selects, '
+                       'compares, integer address math, moves, DPP.',
+           'phases': {names.get(k, str(k)): {c: table[k][c] for c in cols if table[k][c]} for k in sorted(table) if not (k % 2 and k != 25)},
+           'loop_total': {c: tot[c] for c in cols if tot[c]},
+           'loop_vector_arithmetic': sum(tot[c] for c in arith),
+           'loop_vector_non_arithmetic': sum(tot[c] for c in ('dpp', 'cnd', 'mov', 'cmp', 'vint'))}
+    json.dump(out, open(sys.argv[3], 'w'), indent=1)
