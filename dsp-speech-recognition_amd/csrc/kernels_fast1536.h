@@ -501,65 +501,11 @@ static inline bool fast1536_shape_ok(const dsp_plan_desc* d) {
            d->nfilt <= 16 * F1536_MAX_NI && d->numcep >= 1 && d->numcep <= 16;
 }
 
-// LDS cycles of one ds_read_b128 wave instruction whose lane l reads 16 bytes at float address addr[l]
-// (gfx950: four groups of 16 lanes, 64 banks; lanes of a group serialise on a bank they hit at different
-// addresses).  4 = conflict free.  Same model as tools/lds_sim.py.
-static inline int f1536_b128_cycles(const int (&addr)[64]) {
-    static const int grp[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
-                                   {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
-                                   {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
-                                   {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
-    int total = 0;
-    for (int g = 0; g < 4; ++g) {
-        int worst = 1;
-        for (int bank = 0; bank < 64; bank += 4) {
-            int seen[16], ns = 0;
-            for (int q = 0; q < 16; ++q) {
-                const int a = addr[grp[g][q]];
-                if ((a & 63) != bank) continue;
-                bool dup = false;
-                for (int k = 0; k < ns; ++k) dup |= seen[k] == a;
-                if (!dup) seen[ns++] = a;
-            }
-            if (ns > worst) worst = ns;
-        }
-        total += worst;
-    }
-    return total;
-}
-
-// The mel stage gives every lane one slot (a run of `cap` bins of one filter) and reads the slots' bins
-// of all four frames as b128 vectors.  Which lane owns which slot is free: a deterministic local search
-// over that assignment (and over the start bins of unused lanes) minimises the bank conflicts of those
-// reads -- equal-length slots dealt in order put lanes l and l + 16 on the same banks (11 instead of 4
-// cycles per read for the 48 kHz / 26-filter plan).
-static inline void f1536_assign_slots(int (&start)[64], int n_used, int (&lane_of_slot)[64]) {
-    int perm[64];                       // perm[lane] = slot
-    for (int l = 0; l < 64; ++l) perm[l] = l;
-    uint32_t rng = 0x2545F491u;
-    auto rnd = [&](uint32_t n) { rng = rng * 1664525u + 1013904223u; return (rng >> 8) % n; };
-    auto cost = [&]() {
-        int addr[64];
-        for (int l = 0; l < 64; ++l) addr[l] = start[perm[l]];
-        return f1536_b128_cycles(addr);
-    };
-    int cur = cost();
-    for (int it = 0; it < 20000 && cur > 16; ++it) {
-        if (n_used < 64 && rnd(4) == 0) {           // move an unused slot to another bank quad
-            const int sl = n_used + (int)rnd(64 - n_used), old = start[sl];
-            start[sl] = 4 * (int)rnd(16);
-            const int c2 = cost();
-            if (c2 <= cur) cur = c2; else start[sl] = old;
-            continue;
-        }
-        const int a = rnd(64), b = rnd(64);
-        std::swap(perm[a], perm[b]);
-        const int c2 = cost();
-        if (c2 <= cur) cur = c2; else std::swap(perm[a], perm[b]);
-    }
-    for (int l = 0; l < 64; ++l) lane_of_slot[perm[l]] = l;
-}
-
+// (Rounds 1-2 dealt the mel slots to lanes by a local search over a bank-conflict model of ds_read_b128 -- four groups
+// of 16 lanes, 64 banks: 11 -> 8 modelled cycles per read.  Round 3 measured it away: with the search and with slots
+// dealt in order the kernel shows the SAME SQ_LDS_BANK_CONFLICT (6 963 200 per dispatch, to the unit), the same
+// SQ_LDS_IDX_ACTIVE and the same time (profiles/r3_f1536_conflicts.txt).  The counter -- and the clock -- do not see
+// what that model predicts for these reads, so the slots are dealt in order and the search is gone.)
 static inline int fast1536_plan_init(dsp_plan* p, const dsp_plan_desc* d, const int32_t* mel_off) {
     p->d_fast1536 = nullptr;
     if (!fast1536_shape_ok(d)) return DSP_OK;
@@ -630,7 +576,7 @@ static inline int fast1536_plan_init(dsp_plan* p, const dsp_plan_desc* d, const 
             }
         }
         for (int sl = n_slots; sl < 64; ++sl) start[sl] = 0;
-        f1536_assign_slots(start, n_slots, lane_of_slot);
+        for (int sl = 0; sl < 64; ++sl) lane_of_slot[sl] = sl;
         int slot = 0;
         for (int j = 0; j < M; ++j) {
             const int ms = d->h_mel_start[j], cnt = d->h_mel_count[j];
