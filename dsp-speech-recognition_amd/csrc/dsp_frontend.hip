@@ -894,6 +894,16 @@ int dsp_pitch_scores_batch(const float* d_sig, const int64_t* d_sample_offsets, 
     return DSP_OK;
 }
 
+int dsp_pitch_track_batch(const float* d_scores, const int64_t* d_frame_offsets, int32_t n_utt, int32_t n_lags,
+                          int32_t bias, int32_t degree, double* d_pitch, void* stream) {
+    if (!d_scores || !d_frame_offsets || !d_pitch || n_utt <= 0) return fail(DSP_EINVAL, "dsp_pitch_track_batch: bad arguments");
+    if (n_lags <= 0 || n_lags > 256) return fail(DSP_EINVAL, "need 0 < n_lags <= 256");
+    if (degree != 2) return fail(DSP_EINVAL, "smoothing degree %d is not served on the device (the reference only uses 2)", degree);
+    pitch_track_kernel<<<n_utt, 64, 0, (hipStream_t)stream>>>(d_scores, d_frame_offsets, n_lags, bias, d_pitch);
+    HIP_TRY(hipGetLastError());
+    return DSP_OK;
+}
+
 int dsp_endpoint_rule_batch(const double* d_amp_sum, const int32_t* d_zcr, const int64_t* d_frame_offsets,
                             int32_t n_utt, int32_t frame_len, double cfg_frame, double cfg_step,
                             int32_t* d_endpoints, void* stream) {

@@ -266,3 +266,91 @@ __global__ __launch_bounds__(64) void pitch_scores_kernel_v2(
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// The tracker behind the scores: pitch.smooth (pitch.py:157-164), pitch.max_pitch (pitch.py:166-172) and the two
+// octave-repair sweeps of pitch.robust_max_pitch (pitch.py:191-206) for a whole batch, one wavefront per utterance.
+// Everything is sequential over the frames of an utterance in the reference, and two of its habits must be kept:
+//   * smooth() works IN PLACE: row i becomes the mean of rows [max(i - 2, 0), right) where rows below i are already
+//     smoothed and `right = i + 2 if i + 2 < T else T - 1` (so the last rows average over a window that EXCLUDES
+//     the last row, and a one-frame utterance averages over nothing: NaN, whose arg-max is index 0);
+//   * numpy's mean adds the rows in order and divides once; arg-max takes the first maximum (the first NaN if any).
+// fp64 throughout, as the reference (its scores are this library's fp32 scores promoted to double).
+// ------------------------------------------------------------------------------------------------
+#define PITCH_TRACK_LDS_FRAMES 2048   // pitch values of an utterance kept in LDS for the repair sweeps (global memory beyond)
+
+__device__ __forceinline__ void pitch_argmax_combine(double& v, int& ix, double ov, int oix) {
+    // numpy.argmax order: a NaN beats everything, then the larger value, then the smaller index
+    const bool vn = v != v, on = ov != ov;
+    const bool take = (on && !vn) || (on == vn && (ov > v || (ov == v && oix < ix))) || (on && vn && oix < ix);
+    if (take) { v = ov; ix = oix; }
+}
+
+__global__ __launch_bounds__(64) void pitch_track_kernel(const float* __restrict__ scores,
+                                                         const int64_t* __restrict__ frame_off, int32_t n_lags,
+                                                         int32_t bias, double* __restrict__ pitch) {
+    __shared__ double s_pitch[PITCH_TRACK_LDS_FRAMES];
+    const int u = blockIdx.x, lane = threadIdx.x;
+    const int64_t base = frame_off[u];
+    const int T = (int)(frame_off[u + 1] - base);
+    if (T <= 0) return;
+    const float* sc = scores + base * n_lags;
+    double* out = pitch + base;
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    double p2[4], p1[4];                    // smoothed rows i - 2 and i - 1 (lags lane, lane + 64, ...)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p2[k] = p1[k] = 0.0;
+    for (int i = 0; i < T; ++i) {
+        const int left = i - 2 >= 0 ? i - 2 : 0;
+        const int right = i + 2 < T ? i + 2 : T - 1;          // exclusive
+        const int cnt = right - left;
+        double cur[4];
+        double bv = -__longlong_as_double(0x7ff0000000000000ll);   // -inf, index "none": loses to every real candidate
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int lag = lane + 64 * k;
+            double acc = qnan;
+            if (lag < n_lags && cnt > 0) {
+                bool have = false;
+                acc = 0.0;
+                for (int r = left; r < right; ++r) {          // rows in order, as numpy's add.reduce over axis 0
+                    const double v = r == i - 2 ? p2[k] : (r == i - 1 ? p1[k] : (double)sc[(int64_t)r * n_lags + lag]);
+                    acc = have ? acc + v : v;
+                    have = true;
+                }
+                acc = acc / (double)cnt;
+            }
+            cur[k] = acc;
+            if (lag < n_lags) pitch_argmax_combine(bv, bi, acc, lag);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            pitch_argmax_combine(bv, bi, ov, oi);
+        }
+        if (lane == 0) {
+            const double p = 1.0 / (0.0001 * (double)(bias + bi));        // pitch.py:169-170
+            if (i < PITCH_TRACK_LDS_FRAMES) s_pitch[i] = p; else out[i] = p;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { p2[k] = p1[k]; p1[k] = cur[k]; }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        auto get = [&](int i) { return i < PITCH_TRACK_LDS_FRAMES ? s_pitch[i] : out[i]; };
+        auto put = [&](int i, double v) { if (i < PITCH_TRACK_LDS_FRAMES) s_pitch[i] = v; else out[i] = v; };
+        const double C = 50.0;
+        for (int i = 1; i < T; ++i) {                          // pitch.py:199-201
+            const double p = get(i);
+            if (fabs(2.0 * p - get(i - 1)) < C && p < 170.0) put(i, 2.0 * p);
+        }
+        for (int i = T - 2; i > 0; --i) {                      // pitch.py:202-204
+            const double p = get(i);
+            if (fabs(2.0 * p - get(i + 1)) < C && p < 170.0) put(i, 2.0 * p);
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < T && i < PITCH_TRACK_LDS_FRAMES; i += 64) out[i] = s_pitch[i];
+}

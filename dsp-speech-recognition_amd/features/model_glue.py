@@ -215,12 +215,21 @@ class ModelFeatureBatch:
         clips.  The tracker's score kernel is batched per clip; smoothing, arg-max and octave repair are the
         reference's sequential host logic, so this stream downloads the clips and loops over them."""
         import torch
+        from .pitch import downsampling, pitch_tracks_batch
         B = lay.n_utt
         dst = lay.d_dst_off.download((B + 1,), np.int64, st)
         clips = lay.d_trim.download((int(dst[-1]),), np.float32, st)
+        # pitch.pitch_detect_sr for the whole batch: decimation to 10 kHz on the host (an index selection,
+        # preprocess.py:21-28), then scores, smoothing, arg-max and octave repair on the device in two launches
+        cfg = _endpoint.cfg
+        L, S = int(10000 * cfg.frame), int(cfg.step * 10000)
+        downs = [downsampling(clips[dst[b]:dst[b + 1]], self.rate, 10000) for b in range(B)]
+        so10 = np.concatenate([[0], np.cumsum([len(d) for d in downs])]).astype(np.int64)
+        pitch, fo = pitch_tracks_batch(np.concatenate(downs) if so10[-1] else np.zeros(0, dtype=np.float32), so10, L, S)
         out = np.zeros((self.max_len, B, 2), dtype=np.float32)
         for b in range(B):
-            p0, p1 = feature_extract_pitch(clips[dst[b]:dst[b + 1]].astype(np.float64), self.rate)
+            p0 = (pitch[fo[b]:fo[b + 1]] / 150).reshape(-1, 1)          # model.py:93
+            p1 = deviation(p0).reshape(-1, 1)                            # model.py:94
             n0, n1 = min(len(p0), self.max_len), min(len(p1), self.max_len)
             out[:n0, b, 0] = p0[:n0, 0]
             out[:n1, b, 1] = p1[:n1, 0]

@@ -111,10 +111,31 @@ def robust_max_pitch(g, bias=20):
     return pitch
 
 
+def pitch_tracks_batch(sig10k, sample_offsets, L, S, rate=10000):
+    """pitch.pitch_detect_sr's whole per-utterance chain for concatenated 10 kHz signals, on the device: frame scores
+    (dsp_pitch_scores_batch), then smoothing in place, arg-max and the two octave-repair sweeps
+    (dsp_pitch_track_batch; pitch.py:157-206).  Returns (pitch [sum T_b] in Hz, fp64, frame_offsets)."""
+    nat.require_device()
+    lib = nat.load()
+    so = np.ascontiguousarray(sample_offsets, dtype=np.int64)
+    fo = nat.frame_offsets(so, L, S)
+    x = np.ascontiguousarray(sig10k, dtype=np.float32).reshape(-1)
+    d_x = nat.device_array('pitch_sig', x if x.size else np.zeros(1, dtype=np.float32))
+    d_so = nat.device_array('pitch_so', so)
+    d_fo = nat.device_array('pitch_fo', fo)
+    n_lags = MAX_SHIFT - MIN_SHIFT
+    d_scores = nat.SCRATCH.get('pitch_scores', int(fo[-1]) * n_lags * 4)
+    d_pitch = nat.SCRATCH.get('pitch_track', int(fo[-1]) * 8)
+    nat.check(lib.dsp_pitch_scores_batch(d_x.ptr, d_so.ptr, d_fo.ptr, len(so) - 1, int(fo[-1]), 0, int(L), int(S),
+                                         _device_taps(L, rate).ptr, 1, MIN_SHIFT, MAX_SHIFT, d_scores.ptr, None))
+    nat.check(lib.dsp_pitch_track_batch(d_scores.ptr, d_fo.ptr, len(so) - 1, n_lags, MIN_SHIFT, 2, d_pitch.ptr, None))
+    return d_pitch.download((int(fo[-1]),), np.float64), fo
+
+
 def pitch_detect_sr(sig, rate, winlen=0.0512, step=0.01):
     """pitch.py:96-110 -> (pitch per frame in Hz, frames of the 10 kHz signal)."""
     s = downsampling(np.asarray(sig).reshape(-1), rate, 10000)
     L, S = int(10000 * winlen), int(step * 10000)          # to_frames truncates (sigproc.py:19)
-    scores, _ = frame_scores_batch(s, [0, len(s)], L, S)
+    pitch, _ = pitch_tracks_batch(s, [0, len(s)], L, S)
     frames = to_frames(s, 10000, winlen, step)
-    return robust_max_pitch(smooth(scores, 2), bias=20), frames
+    return list(pitch), frames

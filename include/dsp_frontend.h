@@ -298,6 +298,17 @@ int dsp_pitch_scores_batch(const float* d_sig, const int64_t* d_sample_offsets,
                            const float* d_taps, int32_t center_clip, int32_t lag_min, int32_t lag_max,
                            float* d_scores, void* stream);
 
+/*
+ * The tracker behind those scores, for a whole batch (one wavefront per utterance, fp64): pitch.smooth in place
+ * (pitch.py:157-164: running mean over rows [i - 2, i + 2) of which the first two are already smoothed; the
+ * reference's end-of-utterance window and its empty mean for a one-frame utterance included), pitch.max_pitch
+ * (pitch.py:166-172: first arg-max, 1 / (1e-4 (bias + idx))) and the two octave-repair sweeps of
+ * pitch.robust_max_pitch (pitch.py:191-206).  d_scores: [sum T_b, n_lags] fp32 as dsp_pitch_scores_batch writes
+ * them; d_pitch: [sum T_b] fp64, Hz per frame.  degree must be 2 (the only value the reference uses).
+ */
+int dsp_pitch_track_batch(const float* d_scores, const int64_t* d_frame_offsets, int32_t n_utt, int32_t n_lags,
+                          int32_t bias, int32_t degree, double* d_pitch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

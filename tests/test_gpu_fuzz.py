@@ -228,3 +228,40 @@ def test_delta_shapes_beyond_the_tiled_kernel(T, D, N):
     ref = dsp_oracle.delta(x.astype(np.float32).astype(np.float64), N)
     assert got.shape == ref.shape
     assert np.max(np.abs(got - ref)) <= 1e-5 * max(1.0, np.max(np.abs(ref)))
+
+
+def test_device_pitch_tracker_equals_the_reference_sequence():
+    """dsp_pitch_track_batch (in-place smoothing with its end-of-utterance windows, first arg-max, two octave-repair
+    sweeps; pitch.py:157-206) against the host restatement of those loops on random score tables -- utterances of
+    1, 2, 3, 4, 5 frames (empty / short smoothing windows), ties, a NaN score, and one longer than the kernel's LDS
+    buffer.  Pitch values are fp64 and must be IDENTICAL."""
+    import ctypes as C
+    from features import _native as nat
+    from features.pitch import smooth, robust_max_pitch
+    lib = nat.load()
+    rng = np.random.default_rng(77)
+    Ts = [1, 2, 3, 4, 5, 17, 64, 150, 2100, 1, 33]
+    fo = np.concatenate([[0], np.cumsum(Ts)]).astype(np.int64)
+    n_lags = 180
+    sc = rng.random((int(fo[-1]), n_lags)).astype(np.float32)
+    # half-frequency structure so that the repair sweeps fire: a strong peak at lag 2 L next to a weaker one at L
+    for b, T in enumerate(Ts):
+        for t in range(T):
+            lag = int(rng.integers(10, 60))
+            sc[fo[b] + t, lag] += 1.5
+            if rng.random() < 0.5:
+                sc[fo[b] + t, min(2 * lag + 20, n_lags - 1)] += 1.6
+    sc[fo[5] + 3, 7] = sc[fo[5] + 3, 9] = 9.0           # a tie: the first maximum wins
+    sc[fo[6] + 10, 40] = np.nan                        # numpy's arg-max takes the first NaN
+    d_sc = nat.DeviceBuffer(sc.nbytes).upload(sc)
+    d_fo = nat.DeviceBuffer(fo.nbytes).upload(fo)
+    d_p = nat.DeviceBuffer(int(fo[-1]) * 8)
+    nat.check(lib.dsp_pitch_track_batch(d_sc.ptr, d_fo.ptr, len(Ts), n_lags, 20, 2, d_p.ptr, None))
+    got = d_p.download((int(fo[-1]),), np.float64)
+    import warnings
+    for b, T in enumerate(Ts):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')             # the one-frame utterance averages over nothing (NaN), as the reference
+            want = np.asarray(robust_max_pitch(smooth(sc[fo[b]:fo[b + 1]].astype(np.float64), 2), bias=20))
+        assert np.array_equal(got[fo[b]:fo[b + 1]], want), (b, T, np.argwhere(got[fo[b]:fo[b + 1]] != want)[:5])
+    assert lib.dsp_pitch_track_batch(d_sc.ptr, d_fo.ptr, len(Ts), n_lags, 20, 3, d_p.ptr, None) == -1
