@@ -215,27 +215,53 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mfcc1536_kernel(F1536Params P, 
     extern __shared__ __attribute__((aligned(256))) float smem_f[];
     float* const smem = smem_f;
     const int tid = threadIdx.x;
-    // dense batches: touch the first group's samples before the 33 KB of tables are copied, so the HBM latency
-    // of the wave's first loads overlaps the copy (kernels_fast512.h does the same)
-    float warm_ = 0.f;
-    if constexpr (!RAGGED) {
-        const int G0 = (int)blockIdx.x * WAVES + (tid >> 6);
-        if (G0 < (int)P.total_groups) {
-            const int64_t e = (int64_t)(G0 / (int)P.groups_per_utt) * bg.uniform_samples +
-                              (int64_t)(G0 % (int)P.groups_per_utt) * 4 * P.S;
-            const int64_t lim = (int64_t)bg.n_utt * bg.uniform_samples - 4;
+    // Prologue as in kernels_fast512.h: the 33 KB of tables are requested FIRST (inline asm: the compiler would sink the
+    // loads below the touches), then one dword per 16-byte vector of the wave's first group; the copy to LDS and the
+    // barrier wait for the tables only, the touches stay in flight, and every wave waits for its own first fetch.
+    constexpr int TABV = 5;                                    // 5 x 2048 floats cover 40 KB of tables
+    typedef float f1536_v4 __attribute__((ext_vector_type(4)));
+    f1536_v4 tabv_[TABV];
 #pragma unroll
-            for (int r = 0; r < NSTAGE; ++r) {
-                int64_t idx = e + 4 * (tid & 63) + 256 * r;
-                idx = idx < lim ? idx : lim;
-                warm_ += dsp_load_sample<DTYPE>(wave, idx);
-            }
-        }
+    for (int k = 0; k < TABV; ++k) {
+        const int i = tid * 4 + 64 * WAVES * 4 * k;
+        const float* src = P.tables + (i < P.tab_floats ? i : 0);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(tabv_[k]) : "v"(src) : "memory");
     }
-    for (int i = tid * 4; i < P.tab_floats; i += 64 * WAVES * 4)
-        *reinterpret_cast<float4*>(smem + i) = *reinterpret_cast<const float4*>(P.tables + i);
-    __syncthreads();
-    asm volatile("" :: "v"(warm_));   // the values are not used: this only keeps the warming loads alive
+    if constexpr (!RAGGED) {
+        float warm_[NSTAGE];
+        int G0 = (int)blockIdx.x * WAVES + (tid >> 6);
+        G0 = G0 < (int)P.total_groups ? G0 : (int)P.total_groups - 1;
+        const int64_t e = (int64_t)(G0 / (int)P.groups_per_utt) * bg.uniform_samples +
+                          (int64_t)(G0 % (int)P.groups_per_utt) * 4 * P.S;
+        const int64_t lim = (int64_t)bg.n_utt * bg.uniform_samples - 4;
+#pragma unroll
+        for (int r = 0; r < NSTAGE; ++r) {
+            int64_t idx = e + 4 * (tid & 63) + 256 * r;
+            idx = idx < lim ? idx : lim;
+            warm_[r] = dsp_load_sample<DTYPE>(wave, idx);
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NSTAGE) : "memory");   // the tables; the touches stay in flight
+#pragma unroll
+        for (int k = 0; k < TABV; ++k) {
+            const int i = tid * 4 + 64 * WAVES * 4 * k;
+            if (i < P.tab_floats) *reinterpret_cast<f1536_v4*>(smem + i) = tabv_[k];
+        }
+        for (int i = tid * 4 + 64 * WAVES * 4 * TABV; i < P.tab_floats; i += 64 * WAVES * 4)
+            *reinterpret_cast<float4*>(smem + i) = *reinterpret_cast<const float4*>(P.tables + i);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NSTAGE; ++r) asm volatile("" :: "v"(warm_[r]));   // not used: keeps the touches alive
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < TABV; ++k) {
+            const int i = tid * 4 + 64 * WAVES * 4 * k;
+            if (i < P.tab_floats) *reinterpret_cast<f1536_v4*>(smem + i) = tabv_[k];
+        }
+        for (int i = tid * 4 + 64 * WAVES * 4 * TABV; i < P.tab_floats; i += 64 * WAVES * 4)
+            *reinterpret_cast<float4*>(smem + i) = *reinterpret_cast<const float4*>(P.tables + i);
+        __syncthreads();
+    }
     const float* s_win = smem;
     const float2* s_w3 = reinterpret_cast<const float2*>(smem + P.off_w3);
     const float2* s_tw = reinterpret_cast<const float2*>(smem + P.off_tw);
