@@ -508,20 +508,25 @@ def main():
     if world > 1 and not args.no_gather and not REHEARSE:
         from features.distributed import gather_features
         share_out, share = share_launch(dev, plan, reps=10)
-        rows, _ = gather_features(share_out, dst=0)          # warm-up (communicator set-up, allocations)
-        del rows
-        sync_all()
-        g0 = time.perf_counter()
-        rows, counts = gather_features(share_out, dst=0)
-        sync_all()
-        gms = max_over_ranks((time.perf_counter() - g0) * 1e3)
+        share_ms = max_over_ranks(share['ms_per_launch'])
         nbytes = SHARE_UTT * T * D * 4
-        gather = {'collective': 'rccl gather to rank 0 (grouped send/recv, features/distributed.py::gather_features(dst=0))',
-                  'bytes_per_rank': nbytes, 'ms': gms, 'root_ingest_GBps': (world - 1) * nbytes / gms / 1e6,
-                  'share_launch_ms': max_over_ranks(share['ms_per_launch']),
-                  'share_frames_per_s_all_ranks': world * SHARE_UTT * T / max_over_ranks(share['ms_per_launch']) * 1e3,
-                  'rows_at_root': None if rows is None else int(rows.shape[0])}
-        del rows, share_out
+        gather = {'share_launch_ms': share_ms, 'share_frames_per_s_all_ranks': world * SHARE_UTT * T / share_ms * 1e3,
+                  'bytes_per_rank': nbytes}
+        try:      # the collective never ran on more than one GPU before the driver's run: its failure must not cost the line
+            rows, _ = gather_features(share_out, dst=0)          # warm-up (communicator set-up, allocations)
+            del rows
+            sync_all()
+            g0 = time.perf_counter()
+            rows, counts = gather_features(share_out, dst=0)
+            sync_all()
+            gms = max_over_ranks((time.perf_counter() - g0) * 1e3)
+            gather.update({'collective': 'rccl gather to rank 0 (grouped send/recv, features/distributed.py::gather_features(dst=0))',
+                           'ms': gms, 'root_ingest_GBps': (world - 1) * nbytes / gms / 1e6,
+                           'rows_at_root': None if rows is None else int(rows.shape[0])})
+            del rows
+        except Exception as exc:                                 # noqa: BLE001 -- reported in the line
+            gather['error'] = repr(exc)[:300]
+        del share_out
     per_rank_ms = None
     if world > 1:
         mine = torch.tensor([float(np.median([b[1] for b in blocks])) / args.steps], dtype=torch.float64, device=cdev)
