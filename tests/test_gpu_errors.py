@@ -57,6 +57,44 @@ def test_status_codes_and_messages(env):
     assert res.shape == (99, 39) and np.isfinite(res).all()
 
 
+def test_round3_entry_points_reject_bad_arguments(env):
+    """dsp_layout_* / dsp_*_segments_batch / dsp_pitch_track_batch: NULL handles, empty batches and too small a work
+    buffer come back as DSP_EINVAL with a message -- before any launch."""
+    import ctypes as C
+    nat, lib, plan = env
+    h = plan.plan.handle
+    so = np.array([0, 9000, 20000], dtype=np.int64)
+    d_so = nat.DeviceBuffer(so.nbytes).upload(so)
+    fo = nat.frame_offsets(so, 480, 160)
+    d_fo = nat.DeviceBuffer(fo.nbytes).upload(fo)
+    out = C.c_void_p(0)
+    assert lib.dsp_layout_create(None, 2, int(fo[-1]), 480, 160, None, C.byref(out)) == -1
+    assert lib.dsp_layout_create(d_fo.ptr, 0, int(fo[-1]), 480, 160, None, C.byref(out)) == -1
+    assert lib.dsp_layout_create(d_fo.ptr, 2, int(fo[-1]), 480, 160, None, C.byref(out)) == 0 and out.value
+    x = nat.DeviceBuffer(2 * 20000).upload(np.zeros(20000, dtype=np.int16))
+    amp, zcr = nat.DeviceBuffer(8 * int(fo[-1])), nat.DeviceBuffer(4 * int(fo[-1]))
+    assert lib.dsp_vad_features_layout_batch(None, x.ptr, nat.WAVE_I16, d_so.ptr, d_fo.ptr, 0, amp.ptr, zcr.ptr, None) == -1
+    assert lib.dsp_vad_features_layout_batch(out.value, x.ptr, nat.WAVE_I16, d_so.ptr, d_fo.ptr, 0, None, zcr.ptr, None) == -1
+    assert lib.dsp_vad_features_layout_batch(out.value, x.ptr, nat.WAVE_I16, d_so.ptr, d_fo.ptr, 0, amp.ptr, zcr.ptr, None) == 0
+    assert lib.dsp_layout_destroy(out.value) == 0 and lib.dsp_layout_destroy(None) == 0
+    nbytes = C.c_size_t(0)
+    assert lib.dsp_segments_workspace_bytes(None, 2, 200, C.byref(nbytes)) == -1
+    assert lib.dsp_segments_workspace_bytes(h, 2, 200, C.byref(nbytes)) == 0 and nbytes.value > 200 * 13 * 4
+    seg = nat.DeviceBuffer(32).upload(np.array([[100, 8000], [0, 11000]], dtype=np.int64))
+    mfo = nat.DeviceBuffer(24).upload(nat.frame_offsets(np.array([0, 7900, 18900], dtype=np.int64), 400, 160))
+    work = nat.DeviceBuffer(int(nbytes.value))
+    res = nat.DeviceBuffer(200 * 39 * 4)
+    args = (h, x.ptr, nat.WAVE_I16, d_so.ptr, seg.ptr, mfo.ptr, 2, 200, 2, 1)
+    assert lib.dsp_mfcc_delta_segments_batch(*args, work.ptr, 64, res.ptr, None) == -1      # work buffer too small
+    assert 'work buffer' in _msg(lib)
+    assert lib.dsp_mfcc_delta_segments_batch(*args, None, int(nbytes.value), res.ptr, None) == -1
+    assert lib.dsp_mfcc_delta_segments_batch(*args[:8], 0, 1, work.ptr, int(nbytes.value), res.ptr, None) == -1   # delta N < 1
+    assert lib.dsp_mfcc_delta_segments_batch(*args, work.ptr, int(nbytes.value), res.ptr, None) == 0
+    assert lib.dsp_pitch_track_batch(None, d_fo.ptr, 2, 180, 20, 2, amp.ptr, None) == -1
+    assert lib.dsp_pitch_track_batch(x.ptr, d_fo.ptr, 2, 300, 20, 2, amp.ptr, None) == -1
+    nat.check(lib.dsp_stream_synchronize(None))
+
+
 def test_plan_creation_rejects_bad_descriptions(env):
     nat, lib, _ = env
     from features import _plan

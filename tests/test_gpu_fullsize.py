@@ -46,6 +46,10 @@ def test_config3_share_dense(plan):
         assert np.array_equal(out[r], out[0]), r
     first, _ = plan.mfcc_batch(base[:1024], delta_n=2)
     assert np.array_equal(out[0][:1024 * T], first)
+    # ... and so do 8 utterances on their own, which take the OTHER form of the step (MFCC kernel + delta rows kernel;
+    # the big launches are the one fused kernel): the rows do not depend on which kernels produced them
+    few, _ = plan.mfcc_batch(base[:8], delta_n=2)
+    assert np.array_equal(out[0][:8 * T], few)
     sums_big = out[0].reshape(DISTINCT, T * 39).astype(np.float64).sum(axis=1)
     small, _ = plan.mfcc_batch(base, delta_n=2)
     sums_small = small.reshape(DISTINCT, T * 39).astype(np.float64).sum(axis=1)
