@@ -13,6 +13,7 @@
 #include "kernels_generic.h"
 #include "kernels_fast512.h"
 #include "kernels_fast1536.h"
+#include "kernels_mfma512.h"
 #include "kernels_vad.h"
 #include "kernels_pitch.h"
 
@@ -307,6 +308,7 @@ int dsp_plan_create(const dsp_plan_desc* d, dsp_plan** out) {
     }
     if (rc == DSP_OK) rc = fast512_plan_init(p, d, off.data());
     if (rc == DSP_OK && d->nfilt > 0 && d->numcep > 0) rc = fast1536_plan_init(p, d, off.data());
+    if (rc == DSP_OK && d->nfilt > 0 && d->numcep > 0 && p->d_fast) rc = mfma512_plan_init(p, d);
     if (rc != DSP_OK) { dsp_plan_destroy(p); return rc; }
     *out = p;
     return DSP_OK;
@@ -318,6 +320,7 @@ int dsp_plan_destroy(dsp_plan* p) {
     for (void* b : bufs) (void)hipFree(b);
     fast512_plan_free(p);
     fast1536_plan_free(p);
+    mfma512_plan_free(p);
     delete p;
     return DSP_OK;
 }
@@ -393,6 +396,11 @@ static int features_batch_impl(const dsp_plan* plan, const void* d_wave, int wav
     if (uniform_samples > 0 && bg.uniform_frames * n_utt != n_frames_total)
         return fail(DSP_EINVAL, "n_frames_total %lld != n_utt*T (%d*%lld)", (long long)n_frames_total, n_utt, (long long)bg.uniform_frames);
     hipStream_t st = (hipStream_t)stream;
+    if (out_kind == DSP_OUT_MFCC && !g_force_generic && !pre && mfma512_applicable(plan, bg, wave_dtype, 0)) {
+        const int mrc = mfma512_launch(plan, d_wave, wave_dtype, bg, 0, d_out, ld_out, st);   // dense batches: matrix-pipe kernel
+        if (mrc == DSP_OK) return DSP_OK;
+        if (mrc < 0) return fail(mrc, "matrix-pipe MFCC kernel launch failed");
+    }
     if (out_kind == DSP_OUT_MFCC && !g_force_generic && (plan->d_fast || plan->d_fast1536)) {
         BatchGeom fg = bg;
         const void* fw = d_wave;
@@ -501,6 +509,11 @@ int dsp_mfcc_delta_batch(const dsp_plan* plan, const void* d_wave, int wave_dtyp
         if (uniform_frames * n_utt != n_frames_total)
             return fail(DSP_EINVAL, "n_frames_total %lld != n_utt*T (%d*%lld)", (long long)n_frames_total, n_utt, (long long)uniform_frames);
         const BatchGeom fbg = make_geom(nullptr, nullptr, n_utt, n_frames_total, uniform_samples, plan->L, plan->S);
+        if (mfma512_applicable(plan, fbg, wave_dtype, delta_n)) {
+            const int mrc = mfma512_launch(plan, d_wave, wave_dtype, fbg, delta_n, d_out, 3 * (int64_t)C, st);
+            if (mrc == DSP_OK) return DSP_OK;
+            if (mrc < 0) return fail(mrc, "matrix-pipe MFCC + delta kernel launch failed");
+        }
         const int frc = fast512_launch_fused(plan, d_wave, wave_dtype, fbg, delta_n, d_out, st);
         if (frc == DSP_OK) return DSP_OK;
         if (frc < 0) return fail(frc, "fused MFCC + delta kernel launch failed");

@@ -1,0 +1,596 @@
+// NFFT = 512 feature kernel on the matrix pipe (gfx950): waveform -> MFCC (+ delta, delta-delta) rows.
+// Replaces, for dense batches, the reference's per-utterance chain  sigproc.preemphasis (sigproc.py:178-185) ->
+// framesig * window (sigproc.py:66-98) -> powspec (sigproc.py:136-158) -> fbank / mfcc (base.py:8-32, 60-68) ->
+// delta (base.py:70-79), like kernels_fast512.h, but with the DFT, the mel filterbank and the DCT as dense products
+// on v_mfma_f32_16x16x32_{f16,bf16} (tables and operand maps: mfma512_tables.h; numerics study:
+// tools/mfma_numerics.py, tools/mfma512_emul.py).
+//
+// Why: the vector-pipe kernel needs 12.5 k lane-ops per frame and is latency bound at 0.23 of the HBM roofline
+// (DESIGN 4.3).  Here the butterflies are gone; what the vector pipe still does per frame is the fp16 / bf16
+// (hi, lo) splitting of the operands, the power spectrum and the delta rows.
+//
+// Work unit: a TILE = 16 consecutive frames of ONE utterance; lane l = (frame n = l & 15, group g = l >> 4).
+// One wave per SIMD (512 registers: the stage-1 results of a tile, 128 packed registers, stay in registers);
+// a wave owns whole utterances, so nothing is exchanged between waves and the delta window never leaves the wave.
+//  1. staging: the tile's samples (15 S + L, read ONCE per tile through a bounds-checked buffer descriptor: samples
+//     before the utterance and beyond its end read as zero, which IS the reference's zero padding), pre-emphasised,
+//     scaled by a power of two from the tile's largest sample, split into fp16 hi + lo and stored TRANSPOSED in LDS:
+//     plane n2 holds samples 16 r + n2, so a frame's K operand (n1 = 0..31) is contiguous;
+//  2. stage 1: per column n2 six MFMAs (2 row tiles x 3 products) -> (re, im) pairs packed to fp16 hi / lo;
+//  3. a 4 x 4 transpose across the lane groups (v_permlane32_swap / v_permlane16_swap), so that stage 2 finds the
+//     n2 index on the K side;
+//  4. stage 2 per DFT row (six MFMAs), power, bf16 hi / lo, mel blocks (only the non-zero 16 x 32 blocks);
+//  5. log2, DCT * lifter (six MFMAs), scale correction, cepstra into a 32-frame LDS ring;
+//  6. delta / delta-delta from the ring (rows trail the computation by 4 frames), rows copied out contiguously.
+#pragma once
+
+#include "dsp_common.h"
+#include "mfma512_tables.h"
+
+#include <type_traits>
+
+typedef _Float16 m512_h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 m512_b8 __attribute__((ext_vector_type(8)));
+typedef float m512_f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t m512_u4 __attribute__((ext_vector_type(4)));
+typedef _Float16 m512_h2 __attribute__((ext_vector_type(2)));
+typedef float m512_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 m512_b2 __attribute__((ext_vector_type(2)));
+
+#define M512_WAVES 4
+#define M512_RING 32          // frames in the cepstra / delta rings
+#define M512_OBUF_ROW 48      // floats per row of the output staging buffer: 3 x 16
+
+struct M512Params {
+    const uint8_t* tables;
+    M512Layout lay;
+    int32_t L, S, C, append_energy;
+    float preemph;
+    int32_t delta_n;       // 0: cepstra only ([sum T, ld_out]); 1, 2: rows [sum T, 3 C]
+    float inv_den;
+    int64_t ld_out;
+    int32_t n_utt;
+    int64_t samples;       // per utterance
+    int64_t frames;        // per utterance
+};
+
+struct Mfma512Plan {
+    uint8_t* d_tables;
+    M512Layout lay;
+    int rq;                // staging rows per lane quarter (template instantiation)
+};
+
+__device__ __forceinline__ void m512_split_f16(float a, float b, uint32_t& hi, uint32_t& lo) {
+    // hi = (f16(a), f16(b)); lo = (f16(a - hi.a), f16(b - hi.b)); the residuals are exact in fp32.
+    // v_fma_mixlo/hi_f16 read the fp16 half directly: 3 instructions per pair (hipcc needs 6).
+    // No reader of these registers may be an MFMA within two issue slots (the callers pack many pairs first).
+    // The conversion is compiler-visible (it is the first reader of an MFMA result or of a load: hipcc pads the
+    // hazard and waits for the data); the two mix instructions depend on it.
+    uint32_t l;
+    const m512_f2 ab = {a, b};
+    const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(ab, m512_h2));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(a));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(b));
+    hi = h;
+    lo = l;
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void m512_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        m512_static_for<I + 1, N>(f);
+    }
+}
+
+__device__ __forceinline__ m512_h8 m512_as_h8(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    m512_u4 u = {a, b, c, d};
+    return __builtin_bit_cast(m512_h8, u);
+}
+__device__ __forceinline__ m512_b8 m512_as_b8(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    m512_u4 u = {a, b, c, d};
+    return __builtin_bit_cast(m512_b8, u);
+}
+
+__device__ __forceinline__ m512_f4 m512_mma3(m512_h8 ah, m512_h8 al, m512_h8 bh, m512_h8 bl, m512_f4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c, 0, 0, 0);
+    return c;
+}
+
+template <int DTYPE>
+__device__ __forceinline__ float m512_buf_load(__amdgpu_buffer_rsrc_t rs, int32_t voff, int32_t soff) {
+    if constexpr (DTYPE == DSP_WAVE_I16) {
+        return (float)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0);
+    } else {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+    }
+}
+
+// Which mel blocks exist is a compile-time pattern (a run-time test per block costs register copies at every join):
+// two row tiles: all 16 blocks; three row tiles: tile 1 (which carries the energy row) in every step, tile 0 only for
+// the lower half of the spectrum (steps 0..3), tile 2 only for the upper half (steps 4..7): 16 blocks.  The table
+// builder refuses a filterbank with weight outside the pattern (mfma512_tables.h).
+template <int NMT>
+__host__ __device__ constexpr bool m512_has_block(int step, int tile) {
+    return NMT <= 2 ? true : (tile == 1 || (tile == 0 && step < 4) || (tile == 2 && step >= 4));
+}
+template <int NMT>
+__host__ __device__ constexpr int m512_block_index(int step, int tile) {
+    int k = 0;
+    for (int st = 0; st < 8; ++st)
+        for (int t = 0; t < NMT; ++t) {
+            if (st == step && t == tile) return k;
+            if (m512_has_block<NMT>(st, t)) ++k;
+        }
+    return k;
+}
+
+// HS: hop in rows of 16 samples; RQ: staging rows per lane quarter (4 RQ >= 15 HS + ceil(L / 16), RQ % 4 == 0);
+// PS: plane stride in halfs (>= 15 HS + 32 and >= 4 RQ, multiple of 4).
+template <int HS, int RQ, int DTYPE, int NMT, bool ROWS>
+__global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params P, const void* __restrict__ wave,
+                                                                      float* __restrict__ out) {
+    constexpr int PS = ((15 * HS + 32 > 4 * RQ ? 15 * HS + 32 : 4 * RQ) + 3) / 4 * 4;
+    constexpr int IMG_BYTES = 16 * PS * 2;
+    constexpr int WAVE_BYTES = 2 * IMG_BYTES + 2 * M512_RING * 16 * 4;
+    constexpr int ESZ = DTYPE == DSP_WAVE_I16 ? 2 : 4;
+    extern __shared__ __attribute__((aligned(16))) uint8_t m512_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int nwb = 16;   // mel blocks of the pattern (m512_has_block)
+    uint8_t* const sA1 = m512_smem;
+    uint8_t* const sW = m512_smem + 65536;
+    uint8_t* const sWave = m512_smem + 65536 + nwb * 2048 + wv * WAVE_BYTES;
+    uint8_t* const imgHi = sWave;
+    uint8_t* const imgLo = sWave + IMG_BYTES;
+    float* const cring = reinterpret_cast<float*>(sWave + 2 * IMG_BYTES);
+    float* const dring = cring + M512_RING * 16;
+    float* const obuf = reinterpret_cast<float*>(imgHi);   // dead between stage 1 and the next staging
+
+    // ---- tables -> LDS (A1, mel blocks), whole image zeroed (rows no staging pass writes must be finite)
+    {
+        const m512_u4* src = reinterpret_cast<const m512_u4*>(P.tables + P.lay.off_a1);
+        m512_u4* dst = reinterpret_cast<m512_u4*>(sA1);
+        for (int i = tid; i < 65536 / 16; i += 64 * M512_WAVES) dst[i] = src[i];
+        const m512_u4* srcw = reinterpret_cast<const m512_u4*>(P.tables + P.lay.off_w);
+        m512_u4* dstw = reinterpret_cast<m512_u4*>(sW);
+        for (int i = tid; i < nwb * 128; i += 64 * M512_WAVES) dstw[i] = srcw[i];
+        m512_u4* z = reinterpret_cast<m512_u4*>(sWave);
+        const m512_u4 zero = {0, 0, 0, 0};
+        for (int i = lane; i < WAVE_BYTES / 16; i += 64) z[i] = zero;
+    }
+    // ---- register-resident operands: stage-2 matrices, DCT, row sums
+    const int g = lane >> 4, n = lane & 15;
+    m512_h8 a2[2][2], a2p[2][2], dmt[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) {
+            a2[u][hl] = reinterpret_cast<const m512_h8*>(P.tables + P.lay.off_a2 + (u * 2 + hl) * 1024)[lane];
+            a2p[u][hl] = reinterpret_cast<const m512_h8*>(P.tables + P.lay.off_a2p + (u * 2 + hl) * 1024)[lane];
+            dmt[u][hl] = reinterpret_cast<const m512_h8*>(P.tables + P.lay.off_dm + (u * 2 + hl) * 1024)[lane];
+        }
+    float rowsum[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rowsum[i] = reinterpret_cast<const float*>(P.tables + P.lay.off_rowsum)[4 * g + i];
+    __syncthreads();
+
+    // lane constants
+    const int q = lane >> 4, p = lane & 15;                          // staging: plane p, rows RQ q + i
+    const int32_t st_goff = (16 * RQ * q + p) * ESZ;                  // byte offset of the lane's first sample in a tile
+    const uint32_t st_loff = 2u * (uint32_t)(p * PS + RQ * q);        // ... and of its first half in a plane image
+    const uint32_t b_loff = 2u * (uint32_t)(HS * n + 8 * g);          // stage 1: the lane's K octet in plane 0
+    // the lane's K octet of plane 0 as LDS pointers: constant offsets fold into the ds_read_b32's offset field, and
+    // volatile keeps hipcc from pairing neighbours into ds_read2_b32 (twice the LDS cycles per byte; the octet starts
+    // at a 4-byte boundary only, so wider reads are not available)
+    typedef __attribute__((address_space(3))) const volatile uint32_t* lds_cvu32;
+    const lds_cvu32 bHi = reinterpret_cast<lds_cvu32>((uint32_t)reinterpret_cast<uintptr_t>(imgHi + b_loff));
+    const lds_cvu32 bLo = reinterpret_cast<lds_cvu32>((uint32_t)reinterpret_cast<uintptr_t>(imgLo + b_loff));
+    const float cpre = P.preemph;
+    const int C = P.C;
+    const int64_t T = P.frames;
+    const int J = (int)((T + 15) >> 4);
+
+    int ooff[12];   // copy-out: element lane + 64 m of a 16-row block of [x | d | dd] rows -> its float in obuf
+#pragma unroll
+    for (int m = 0; m < 12; ++m) {
+        const int e = lane + 64 * m, W3 = 3 * C, fr = e / W3, col = e - fr * W3, part = col / C, cc = col - part * C;
+        ooff[m] = fr < 16 ? fr * M512_OBUF_ROW + part * 16 + cc : 0;
+    }
+
+    const int nw_total = gridDim.x * M512_WAVES, wglob = blockIdx.x * M512_WAVES + wv;
+    const int u_lo = (int)((int64_t)P.n_utt * wglob / nw_total), u_hi = (int)((int64_t)P.n_utt * (wglob + 1) / nw_total);
+
+    for (int utt = u_lo; utt < u_hi; ++utt) {
+        const uint8_t* ubase = reinterpret_cast<const uint8_t*>(wave) + (int64_t)utt * P.samples * ESZ;
+        // x[u]: u < N; prev x[u - 1]: 1 <= u <= N - 1 (u = 0 wraps to a huge offset, u >= N is out of range): both read
+        // as zero outside, which gives y[0] = x[0] and a zero tail AFTER pre-emphasis (sigproc.py:79-91 pads y, not x)
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(ubase), 0, (int32_t)(P.samples * ESZ), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(ubase), 0, (int32_t)((P.samples - 1) * ESZ), 0x00020000);
+        const int64_t row0 = (int64_t)utt * T;                        // first output row of the utterance
+
+        float xs[RQ], xp[RQ];
+        auto fetch = [&](int j) {
+            // the whole offset travels in the VGPR / immediate (the descriptor's range check covers those two only);
+            // unsigned sums, so hipcc folds the constants into the instruction's offset field
+            const uint32_t voff = (uint32_t)st_goff + (uint32_t)(j * 16 * P.S * ESZ);
+            const uint32_t voffp = voff + (uint32_t)(16 * ESZ - ESZ);     // x[u - 1] of row i >= 1: never negative
+            xs[0] = m512_buf_load<DTYPE>(rs_x, (int32_t)voff, 0);
+            xp[0] = m512_buf_load<DTYPE>(rs_p, (int32_t)(voff - (uint32_t)ESZ), 0);   // u = 0 wraps: out of range, reads 0
+#pragma unroll
+            for (int i = 1; i < RQ; ++i) {
+                xs[i] = m512_buf_load<DTYPE>(rs_x, (int32_t)(voff + (uint32_t)(16 * ESZ * i)), 0);
+                xp[i] = m512_buf_load<DTYPE>(rs_p, (int32_t)(voffp + (uint32_t)(16 * ESZ * (i - 1))), 0);
+            }
+        };
+        fetch(0);
+
+        for (int j = 0; j < J; ++j) {
+            // ---------------------------------------------------------------- 1. staging
+            float mx = fabsf(xp[0]);
+#pragma unroll
+            for (int i = 0; i < RQ; i += 2) asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mx) : "v"(xs[i]), "v"(xs[i + 1]));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            const uint32_t mbits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, mx));
+            int esc = 0;
+            if (mbits != 0) {
+                int ex = (int)((mbits >> 23) & 255u) - 127;           // 2^ex <= max < 2^(ex+1); |y| < 2^(ex+2)
+                esc = M512_XBITS - ex - 2;
+                esc = esc > 120 ? 120 : (esc < -120 ? -120 : esc);
+            }
+            const float sc = __builtin_bit_cast(float, (uint32_t)(esc + 127) << 23);
+            const float csc = -cpre * sc;
+            const float corr = (float)(2 * esc + M512_WSH);
+#pragma unroll
+            for (int i = 0; i < RQ; i += 4) {
+                uint32_t h0, l0, h1, l1;
+                const float y0 = fmaf(xp[i], csc, xs[i] * sc), y1 = fmaf(xp[i + 1], csc, xs[i + 1] * sc);
+                const float y2 = fmaf(xp[i + 2], csc, xs[i + 2] * sc), y3 = fmaf(xp[i + 3], csc, xs[i + 3] * sc);
+                m512_split_f16(y0, y1, h0, l0);
+                m512_split_f16(y2, y3, h1, l1);
+                *reinterpret_cast<uint2*>(imgHi + st_loff + 2 * i) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(imgLo + st_loff + 2 * i) = make_uint2(l0, l1);
+            }
+
+            // ---------------------------------------------------------------- 2. stage 1
+            uint32_t Rh[4][4][4], Rl[4][4][4];                        // [n2 >> 2][n2 & 3][i]: (re, im) of row 4 g + i
+            m512_f4 accp[2];
+#pragma unroll
+            for (int n2 = 0; n2 < 16; ++n2) {
+                uint32_t bh[4], bl[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    bh[d] = bHi[(2 * n2 * PS + 4 * d) / 4];
+                    bl[d] = bLo[(2 * n2 * PS + 4 * d) / 4];
+                }
+                const m512_h8 Bh = m512_as_h8(bh[0], bh[1], bh[2], bh[3]), Bl = m512_as_h8(bl[0], bl[1], bl[2], bl[3]);
+                m512_f4 acc[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const m512_h8 ah = reinterpret_cast<const m512_h8*>(sA1 + ((n2 * 2 + t) * 2 + 0) * 1024)[lane];
+                    const m512_h8 al = reinterpret_cast<const m512_h8*>(sA1 + ((n2 * 2 + t) * 2 + 1) * 1024)[lane];
+                    const m512_f4 zero = {0.f, 0.f, 0.f, 0.f};
+                    acc[t] = m512_mma3(ah, al, Bh, Bl, zero);
+                }
+                if (n2 > 0) {   // the previous column's results are packed while this column's products run
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        m512_split_f16(accp[0][i], accp[1][i], Rh[(n2 - 1) >> 2][(n2 - 1) & 3][i], Rl[(n2 - 1) >> 2][(n2 - 1) & 3][i]);
+                }
+                accp[0] = acc[0];
+                accp[1] = acc[1];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) m512_split_f16(accp[0][i], accp[1][i], Rh[3][3][i], Rl[3][3][i]);
+            // the next tile's samples travel while the rest of this tile is computed
+            if (j + 1 < J) fetch(j + 1);
+
+            // ---------------------------------------------------------------- 3. transpose n2-block <-> lane group
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#define M512_SWAP32(a, b) { auto s_ = __builtin_amdgcn_permlane32_swap(a, b, false, false); a = s_[0]; b = s_[1]; }
+#define M512_SWAP16(a, b) { auto s_ = __builtin_amdgcn_permlane16_swap(a, b, false, false); a = s_[0]; b = s_[1]; }
+                    M512_SWAP32(Rh[0][qq][i], Rh[2][qq][i]);
+                    M512_SWAP32(Rh[1][qq][i], Rh[3][qq][i]);
+                    M512_SWAP16(Rh[0][qq][i], Rh[1][qq][i]);
+                    M512_SWAP16(Rh[2][qq][i], Rh[3][qq][i]);
+                    M512_SWAP32(Rl[0][qq][i], Rl[2][qq][i]);
+                    M512_SWAP32(Rl[1][qq][i], Rl[3][qq][i]);
+                    M512_SWAP16(Rl[0][qq][i], Rl[1][qq][i]);
+                    M512_SWAP16(Rl[2][qq][i], Rl[3][qq][i]);
+                }
+            // now R?[sig][qq][i] in lane group gam = (re, im) of slot 4 sig + i at n2 = 4 gam + qq
+
+            // ---------------------------------------------------------------- 4. stage 2, power, mel
+            m512_f4 eacc[NMT];
+#pragma unroll
+            for (int t = 0; t < NMT; ++t) eacc[t] = m512_f4{0.f, 0.f, 0.f, 0.f};
+            uint32_t Ph[8][4], Pl[8][4];   // [mel step 2 ip + (s >> 3)][dword (s & 7) >> 1]: powers of slots (s, s + 1) as bf16
+            float pwp[4];                   // powers of the even slot of a pair
+            m512_f4 rep, imp;               // stage-2 results of the previous slot
+            // power + bf16 split of slot s (from rep / imp), and, when an octet of slots is complete, its mel blocks
+            auto finish_slot = [&](auto sc_) {
+                constexpr int s = decltype(sc_)::value;
+                float pw[4];
+#pragma unroll
+                for (int ip = 0; ip < 4; ++ip) pw[ip] = fmaf(rep[ip], rep[ip], imp[ip] * imp[ip]);
+                if constexpr ((s & 1) == 0) {
+#pragma unroll
+                    for (int ip = 0; ip < 4; ++ip) pwp[ip] = pw[ip];
+                } else {
+#pragma unroll
+                    for (int ip = 0; ip < 4; ++ip) {
+                        const m512_f2 v = {pwp[ip], pw[ip]};
+                        const uint32_t hu = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, m512_b2));
+                        const float ha = __builtin_bit_cast(float, hu << 16), hbv = __builtin_bit_cast(float, hu & 0xffff0000u);
+                        const m512_f2 r = {v[0] - ha, v[1] - hbv};
+                        Ph[2 * ip + (s >> 3)][(s & 7) >> 1] = hu;
+                        Pl[2 * ip + (s >> 3)][(s & 7) >> 1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, m512_b2));
+                    }
+                }
+                if constexpr ((s & 7) == 7) {
+                    constexpr int h = s >> 3;
+#pragma unroll
+                    for (int ip = 0; ip < 4; ++ip) {
+                        constexpr int dummy = 0; (void)dummy;
+                        const int step = 2 * ip + h;
+                        const m512_b8 ph = m512_as_b8(Ph[step][0], Ph[step][1], Ph[step][2], Ph[step][3]);
+                        const m512_b8 pl = m512_as_b8(Pl[step][0], Pl[step][1], Pl[step][2], Pl[step][3]);
+#pragma unroll
+                        for (int t = 0; t < NMT; ++t) {
+                            if (m512_has_block<NMT>(step, t)) {
+                                const int bi = m512_block_index<NMT>(step, t);
+                                const m512_b8 wh = reinterpret_cast<const m512_b8*>(sW + bi * 2048)[lane];
+                                const m512_b8 wl = reinterpret_cast<const m512_b8*>(sW + bi * 2048 + 1024)[lane];
+                                eacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ph, eacc[t], 0, 0, 0);
+                                eacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, pl, eacc[t], 0, 0, 0);
+                                eacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ph, eacc[t], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            };
+            auto run_slot = [&](auto sc_) {
+                constexpr int s = decltype(sc_)::value;
+                constexpr int sig = s >> 2, i = s & 3;
+                const m512_h8 Bh = m512_as_h8(Rh[sig][0][i], Rh[sig][1][i], Rh[sig][2][i], Rh[sig][3][i]);
+                const m512_h8 Bl = m512_as_h8(Rl[sig][0][i], Rl[sig][1][i], Rl[sig][2][i], Rl[sig][3][i]);
+                const m512_f4 zero = {0.f, 0.f, 0.f, 0.f};
+                m512_f4 re, im;
+                if constexpr (s == 0) {
+                    re = m512_mma3(a2p[0][0], a2p[0][1], Bh, Bl, zero);
+                    im = m512_mma3(a2p[1][0], a2p[1][1], Bh, Bl, zero);
+                } else {
+                    re = m512_mma3(a2[0][0], a2[0][1], Bh, Bl, zero);
+                    im = m512_mma3(a2[1][0], a2[1][1], Bh, Bl, zero);
+                }
+                if constexpr (s > 0) finish_slot(std::integral_constant<int, (s > 0 ? s - 1 : 0)>{});
+                rep = re;
+                imp = im;
+            };
+            m512_static_for<0, 16>(run_slot);
+            finish_slot(std::integral_constant<int, 15>{});
+
+            // ---------------------------------------------------------------- 5. log2, DCT * lifter, correction
+            const float zval = P.lay.z_log2_eps + corr;
+            uint32_t leh[3][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}}, lel[3][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};
+#pragma unroll
+            for (int t = 0; t < NMT; ++t) {
+                float le[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) le[i] = eacc[t][i] == 0.f ? zval : __builtin_amdgcn_logf(eacc[t][i]);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const m512_f2 v = {le[2 * k], le[2 * k + 1]};
+                    const m512_h2 hh = __builtin_convertvector(v, m512_h2);
+                    const m512_f2 r = {v[0] - (float)hh[0], v[1] - (float)hh[1]};
+                    const m512_h2 ll = __builtin_convertvector(r, m512_h2);
+                    leh[t][k] = __builtin_bit_cast(uint32_t, hh);
+                    lel[t][k] = __builtin_bit_cast(uint32_t, ll);
+                }
+            }
+            m512_f4 cep = {0.f, 0.f, 0.f, 0.f};
+            cep = m512_mma3(dmt[0][0], dmt[0][1], m512_as_h8(leh[0][0], leh[0][1], leh[1][0], leh[1][1]),
+                            m512_as_h8(lel[0][0], lel[0][1], lel[1][0], lel[1][1]), cep);
+            if (NMT > 2)
+                cep = m512_mma3(dmt[1][0], dmt[1][1], m512_as_h8(leh[2][0], leh[2][1], 0u, 0u), m512_as_h8(lel[2][0], lel[2][1], 0u, 0u), cep);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cep[i] = fmaf(-corr, rowsum[i], cep[i]);
+
+            const int t0 = 16 * j;
+            if constexpr (!ROWS) {
+                // ------------------------------------------------------------ 6a. cepstra only
+                if (t0 + n < T) {
+                    float* o = out + (row0 + t0 + n) * P.ld_out + 4 * g;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (4 * g + i < C) o[i] = cep[i];
+                }
+            } else {
+                // ------------------------------------------------------------ 6b. delta, delta-delta, rows
+                *reinterpret_cast<m512_f4*>(cring + ((t0 + n) & (M512_RING - 1)) * 16 + 4 * g) = cep;
+                const bool last = j == J - 1;
+                const int Ti = (int)T, nd = P.delta_n;
+                const float inv = P.inv_den;
+                const int dlo = j == 0 ? 0 : t0 - 2, dhi = last ? Ti : t0 + 14;
+                const int olo = j == 0 ? 0 : t0 - 4, ohi = last ? Ti : t0 + 12;
+                const int fo = lane & 15, cq = lane >> 4;
+                for (int f0 = dlo; f0 < dhi; f0 += 16) {           // delta of frames [dlo, dhi)
+                    const int f = f0 + fo;
+                    if (f < dhi) {
+                        m512_f4 d = {0.f, 0.f, 0.f, 0.f};
+                        for (int k = 1; k <= nd; ++k) {
+                            const int fa = min(f + k, Ti - 1), fb = max(f - k, 0);
+                            const m512_f4 a = *reinterpret_cast<const m512_f4*>(cring + (fa & (M512_RING - 1)) * 16 + 4 * cq);
+                            const m512_f4 b = *reinterpret_cast<const m512_f4*>(cring + (fb & (M512_RING - 1)) * 16 + 4 * cq);
+                            const float kf = (float)k;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) d[i] = fmaf(kf, a[i] - b[i], d[i]);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) d[i] *= inv;
+                        *reinterpret_cast<m512_f4*>(dring + (f & (M512_RING - 1)) * 16 + 4 * cq) = d;
+                    }
+                }
+                for (int f0 = olo; f0 < ohi; f0 += 16) {           // rows of frames [olo, ohi)
+                    const int f = f0 + fo;
+                    if (f < ohi) {
+                        m512_f4 dd = {0.f, 0.f, 0.f, 0.f};
+                        for (int k = 1; k <= nd; ++k) {
+                            const int fa = min(f + k, Ti - 1), fb = max(f - k, 0);
+                            const m512_f4 a = *reinterpret_cast<const m512_f4*>(dring + (fa & (M512_RING - 1)) * 16 + 4 * cq);
+                            const m512_f4 b = *reinterpret_cast<const m512_f4*>(dring + (fb & (M512_RING - 1)) * 16 + 4 * cq);
+                            const float kf = (float)k;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) dd[i] = fmaf(kf, a[i] - b[i], dd[i]);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) dd[i] *= inv;
+                        float* orow = obuf + fo * M512_OBUF_ROW + 4 * cq;
+                        *reinterpret_cast<m512_f4*>(orow) = *reinterpret_cast<const m512_f4*>(cring + (f & (M512_RING - 1)) * 16 + 4 * cq);
+                        *reinterpret_cast<m512_f4*>(orow + 16) = *reinterpret_cast<const m512_f4*>(dring + (f & (M512_RING - 1)) * 16 + 4 * cq);
+                        *reinterpret_cast<m512_f4*>(orow + 32) = dd;
+                    }
+                    // copy out: rows f0 .. f0 + nr - 1 are contiguous in memory
+                    const int nr = min(16, ohi - f0), ne = nr * 3 * C;
+                    float* dst = out + (row0 + f0) * (int64_t)(3 * C);
+#pragma unroll
+                    for (int m = 0; m < 12; ++m) {
+                        const int e = lane + 64 * m;
+                        if (e < ne) dst[e] = obuf[ooff[m]];
+                    }
+                }
+                // obuf lies over the first planes of the hi image: the rows of those planes that no staging pass
+                // rewrites (4 RQ .. PS - 1, read against zero window rows by the tile's last frames) must be finite again
+                if constexpr (PS > 4 * RQ) {
+                    static_assert((PS - 4 * RQ) == 8, "pad rows are one 16-byte store per plane");
+                    if (lane < 16) *reinterpret_cast<m512_u4*>(imgHi + lane * PS * 2 + 4 * RQ * 2) = m512_u4{0u, 0u, 0u, 0u};
+                }
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------- host side
+#ifndef M512_KERNEL_ONLY
+
+static inline bool mfma512_disabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("DSP_MFMA512");
+        v = (e && e[0] == '0') ? 1 : 0;
+    }
+    return v == 1;
+}
+
+static inline int mfma512_plan_init(dsp_plan* p, const dsp_plan_desc* d) {
+    p->d_mfma = nullptr;
+    if (d->nfft != 512 || d->nfilt < 1 || d->numcep < 1 || !d->h_dct || !d->h_window) return DSP_OK;
+    if (d->frame_step != 160) return DSP_OK;                 // instantiated hop: 10 rows of 16 samples
+    std::vector<uint8_t> blob;
+    M512Layout lay;
+    const int rc = m512_build_tables(d->frame_len, d->frame_step, d->nfft, d->nfilt, d->numcep, d->append_energy, d->h_window,
+                                     d->h_mel_start, d->h_mel_count, d->h_mel_weights, d->h_dct, blob, lay);
+    if (rc != 0) return DSP_OK;                               // not served: the other kernels take the plan
+    Mfma512Plan* mp = new Mfma512Plan();
+    mp->lay = lay;
+    const int rows = 15 * (d->frame_step / 16) + lay.KR;
+    mp->rq = rows <= 176 ? 44 : 48;
+    if (hipMalloc(&mp->d_tables, blob.size()) != hipSuccess) { delete mp; return DSP_EHIP; }
+    if (hipMemcpy(mp->d_tables, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(mp->d_tables);
+        delete mp;
+        return DSP_EHIP;
+    }
+    p->d_mfma = mp;
+    return DSP_OK;
+}
+
+static inline void mfma512_plan_free(dsp_plan* p) {
+    if (!p->d_mfma) return;
+    Mfma512Plan* mp = static_cast<Mfma512Plan*>(p->d_mfma);
+    (void)hipFree(mp->d_tables);
+    delete mp;
+    p->d_mfma = nullptr;
+}
+
+static inline int mfma512_device_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+// dense batches only: every utterance `uniform_samples` long, at least one utterance per wave slot of the chip
+static inline bool mfma512_applicable(const dsp_plan* p, const BatchGeom& bg, int dtype, int delta_n) {
+    if (!p->d_mfma || mfma512_disabled()) return false;
+    if (bg.uniform_samples <= 0 || bg.seg) return false;
+    if (dtype != DSP_WAVE_F32 && dtype != DSP_WAVE_I16) return false;
+    if (delta_n < 0 || delta_n > 2) return false;
+    if (bg.uniform_samples * 4 >= ((int64_t)1 << 31)) return false;
+    if (bg.n_utt < mfma512_device_cus() * M512_WAVES / 2) return false;
+    return true;
+}
+
+template <int RQ, int DTYPE, int NMT, bool ROWS>
+static int mfma512_launch_k(const M512Params& P, const void* d_wave, float* d_out, hipStream_t st) {
+    constexpr int HS = 10;
+    constexpr int PS = ((15 * HS + 32 > 4 * RQ ? 15 * HS + 32 : 4 * RQ) + 3) / 4 * 4;
+    constexpr int WAVE_BYTES = 2 * 16 * PS * 2 + 2 * M512_RING * 16 * 4;
+    const size_t lds = 65536 + (size_t)16 * 2048 + (size_t)M512_WAVES * WAVE_BYTES;
+    if (lds > 163840) return 1;
+    auto kern = mfcc512m_kernel<HS, RQ, DTYPE, NMT, ROWS>;
+    static bool attr_set = false;   // per instantiation
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess)
+            return DSP_EHIP;
+        attr_set = true;
+    }
+    int grid = mfma512_device_cus();
+    const int need = (P.n_utt + M512_WAVES - 1) / M512_WAVES;
+    if (grid > need) grid = need;
+    kern<<<grid, 64 * M512_WAVES, lds, st>>>(P, d_wave, d_out);
+    return hipGetLastError() == hipSuccess ? DSP_OK : DSP_EHIP;
+}
+
+// 0 = launched; 1 = not served (caller falls through); < 0 error
+static inline int mfma512_launch(const dsp_plan* p, const void* d_wave, int dtype, const BatchGeom& bg, int delta_n,
+                                 float* d_out, int64_t ld_out, hipStream_t st) {
+    const Mfma512Plan* mp = static_cast<const Mfma512Plan*>(p->d_mfma);
+    M512Params P;
+    memset(&P, 0, sizeof(P));
+    P.tables = mp->d_tables;
+    P.lay = mp->lay;
+    P.L = p->L; P.S = p->S; P.C = p->C; P.append_energy = p->append_energy;
+    P.preemph = p->preemph;
+    P.delta_n = delta_n;
+    int den = 0;
+    for (int i = 1; i <= delta_n; ++i) den += i * i;
+    P.inv_den = den ? (float)(1.0 / (2.0 * den)) : 0.f;
+    P.ld_out = ld_out;
+    P.n_utt = bg.n_utt;
+    P.samples = bg.uniform_samples;
+    P.frames = bg.uniform_frames;
+    const int nmt = mp->lay.n_mtiles;
+#define M512_LAUNCH(RQ_, DT_, NMT_, ROWS_) return mfma512_launch_k<RQ_, DT_, NMT_, ROWS_>(P, d_wave, d_out, st)
+#define M512_LAUNCH_NMT(RQ_, DT_, ROWS_) \
+    do { if (nmt <= 2) M512_LAUNCH(RQ_, DT_, 2, ROWS_); else M512_LAUNCH(RQ_, DT_, 3, ROWS_); } while (0)
+#define M512_LAUNCH_DT(RQ_, ROWS_) \
+    do { if (dtype == DSP_WAVE_I16) M512_LAUNCH_NMT(RQ_, DSP_WAVE_I16, ROWS_); else M512_LAUNCH_NMT(RQ_, DSP_WAVE_F32, ROWS_); } while (0)
+    if (delta_n > 0) {
+        if (mp->rq == 44) M512_LAUNCH_DT(44, true); else M512_LAUNCH_DT(48, true);
+    } else {
+        if (mp->rq == 44) M512_LAUNCH_DT(44, false); else M512_LAUNCH_DT(48, false);
+    }
+    return 1;
+}
+#endif  // M512_KERNEL_ONLY
