@@ -178,6 +178,22 @@ int dsp_debug_read_stamps(unsigned long long* out, int n) {
 }
 #endif
 
+#ifdef M512_STAMPS
+// diagnostic builds only: per-phase shader-clock sums of mfcc512m_kernel (not declared in the public header)
+int dsp_debug_read_stamps_m512(unsigned long long* out, int n) {
+    static std::vector<unsigned int> h(M512_NSTAMP * 2048);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(m512_stamp_sum), h.size() * 4));
+    for (int i = 0; i < n && i < M512_NSTAMP; ++i) {
+        out[i] = 0;
+        for (int w = 0; w < 2048; ++w) out[i] += h[(size_t)w * M512_NSTAMP + i];
+    }
+    std::fill(h.begin(), h.end(), 0u);
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(m512_stamp_sum), h.data(), h.size() * 4));
+    return DSP_OK;
+}
+#endif
+
 int dsp_plan_has_fast_path(const dsp_plan* plan) { return plan && (plan->d_fast || plan->d_fast1536) ? 1 : 0; }
 
 const char* dsp_last_error(void) { return g_err.c_str(); }

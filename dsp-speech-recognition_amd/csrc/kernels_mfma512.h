@@ -38,6 +38,10 @@ typedef float m512_f2 __attribute__((ext_vector_type(2)));
 typedef __bf16 m512_b2 __attribute__((ext_vector_type(2)));
 
 #define M512_WAVES 4
+// Lanes of a wave hand data to each other through LDS (the LDS queue of a wave is in order).  hipcc reasons per
+// lane: a load whose address it can prove different from an earlier store's IN THE SAME LANE may be hoisted above
+// that store -- this keeps program order at the hand-over points.
+#define M512_LDS_FENCE() asm volatile("" ::: "memory")
 #define M512_RING 32          // frames in the cepstra / delta rings
 #define M512_OBUF_ROW 48      // floats per row of the output staging buffer: 3 x 16
 
@@ -74,6 +78,22 @@ __device__ __forceinline__ void m512_split_f16(float a, float b, uint32_t& hi, u
     hi = h;
     lo = l;
 }
+
+// Diagnostic build (-DM512_STAMPS, tools/kbench_m512.py): per-phase shader-clock sums, one slot per wave.
+#ifdef M512_STAMPS
+#define M512_NSTAMP 16
+__device__ unsigned int m512_stamp_sum[M512_NSTAMP * 2048];
+__device__ __forceinline__ unsigned int m512_clock() {
+    unsigned long long t;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return (unsigned int)t;
+}
+#define M512_STAMP(i) do { const unsigned int now_ = m512_clock(); stamp_acc_[i] += now_ - stamp_prev_; stamp_prev_ = m512_clock(); } while (0)
+#define M512_PIN(x) asm volatile("" : "+v"(x))
+#else
+#define M512_STAMP(i) do {} while (0)
+#define M512_PIN(x) do {} while (0)
+#endif
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void m512_static_for(F&& f) {
@@ -127,15 +147,37 @@ __host__ __device__ constexpr int m512_block_index(int step, int tile) {
     return k;
 }
 
+// The blocks of mel steps 2 ip + h (the steps whose operands an octet of slots completes), in multiplication order.
+template <int NMT>
+__host__ __device__ constexpr int m512_octet_blocks(int h) {
+    int c = 0;
+    for (int ip = 0; ip < 4; ++ip)
+        for (int t = 0; t < NMT; ++t)
+            if (m512_has_block<NMT>(2 * ip + h, t)) ++c;
+    return c;
+}
+template <int NMT>
+__host__ __device__ constexpr int m512_octet_block(int h, int k) {   // -> ip * 4 + tile of the k-th block
+    int c = 0;
+    for (int ip = 0; ip < 4; ++ip)
+        for (int t = 0; t < NMT; ++t)
+            if (m512_has_block<NMT>(2 * ip + h, t)) {
+                if (c == k) return ip * 4 + t;
+                ++c;
+            }
+    return 0;
+}
+
 // HS: hop in rows of 16 samples; RQ: staging rows per lane quarter (4 RQ >= 15 HS + ceil(L / 16), RQ % 4 == 0);
 // PS: plane stride in halfs (>= 15 HS + 32 and >= 4 RQ, multiple of 4).
-template <int HS, int RQ, int DTYPE, int NMT, bool ROWS>
+template <int HS, int RQ, int DTYPE, int NMT, int ND>
 __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params P, const void* __restrict__ wave,
                                                                       float* __restrict__ out) {
     constexpr int PS = ((15 * HS + 32 > 4 * RQ ? 15 * HS + 32 : 4 * RQ) + 3) / 4 * 4;
     constexpr int IMG_BYTES = 16 * PS * 2;
     constexpr int WAVE_BYTES = 2 * IMG_BYTES + 2 * M512_RING * 16 * 4;
     constexpr int ESZ = DTYPE == DSP_WAVE_I16 ? 2 : 4;
+    constexpr bool ROWS = ND > 0;   // ND: delta window (base.py:70-79), 0 = cepstra only
     extern __shared__ __attribute__((aligned(16))) uint8_t m512_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -200,6 +242,12 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
         ooff[m] = fr < 16 ? fr * M512_OBUF_ROW + part * 16 + cc : 0;
     }
 
+#ifdef M512_STAMPS
+    unsigned int stamp_acc_[M512_NSTAMP] = {0}, stamp_prev_ = m512_clock();
+    const unsigned int stamp_t0_ = stamp_prev_;
+    unsigned long long stamp_rt0_;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_rt0_));
+#endif
     const int nw_total = gridDim.x * M512_WAVES, wglob = blockIdx.x * M512_WAVES + wv;
     const int u_lo = (int)((int64_t)P.n_utt * wglob / nw_total), u_hi = (int)((int64_t)P.n_utt * (wglob + 1) / nw_total);
 
@@ -228,13 +276,20 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
         fetch(0);
 
         for (int j = 0; j < J; ++j) {
+            M512_STAMP(0);   // loop overhead / fetch of the first tile
             // ---------------------------------------------------------------- 1. staging
             float mx = fabsf(xp[0]);
 #pragma unroll
             for (int i = 0; i < RQ; i += 2) asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mx) : "v"(xs[i]), "v"(xs[i + 1]));
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-            const uint32_t mbits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, mx));
+            // wave maximum of non-negative floats = maximum of their bit patterns: four DPP steps inside each row of 16
+            // lanes, then the four rows on the scalar side
+            uint32_t mu = __builtin_bit_cast(uint32_t, mx);
+            mu = max(mu, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mu, 0xb1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+            mu = max(mu, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mu, 0x4e, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+            mu = max(mu, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mu, 0x141, 0xf, 0xf, true));   // row_half_mirror
+            mu = max(mu, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mu, 0x140, 0xf, 0xf, true));   // row_mirror
+            const uint32_t mbits = max(max((uint32_t)__builtin_amdgcn_readlane((int)mu, 0), (uint32_t)__builtin_amdgcn_readlane((int)mu, 16)),
+                                       max((uint32_t)__builtin_amdgcn_readlane((int)mu, 32), (uint32_t)__builtin_amdgcn_readlane((int)mu, 48)));
             int esc = 0;
             if (mbits != 0) {
                 int ex = (int)((mbits >> 23) & 255u) - 127;           // 2^ex <= max < 2^(ex+1); |y| < 2^(ex+2)
@@ -255,36 +310,59 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
                 *reinterpret_cast<uint2*>(imgLo + st_loff + 2 * i) = make_uint2(l0, l1);
             }
 
+            M512_LDS_FENCE();
+            M512_STAMP(1);
             // ---------------------------------------------------------------- 2. stage 1
             uint32_t Rh[4][4][4], Rl[4][4][4];                        // [n2 >> 2][n2 & 3][i]: (re, im) of row 4 g + i
             m512_f4 accp[2];
-#pragma unroll
-            for (int n2 = 0; n2 < 16; ++n2) {
-                uint32_t bh[4], bl[4];
+            // the operands of column n2 + 1 are read while the products of column n2 run (one wave per SIMD: nobody
+            // else hides the LDS latency)
+            uint32_t bh[2][4], bl[2][4];
+            m512_h8 ah[2][2], al[2][2];
+            auto load_ops = [&](auto nc_) {
+                constexpr int n2 = decltype(nc_)::value;
+                constexpr int sl = n2 & 1;
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    bh[d] = bHi[(2 * n2 * PS + 4 * d) / 4];
-                    bl[d] = bLo[(2 * n2 * PS + 4 * d) / 4];
+                    bh[sl][d] = bHi[(2 * n2 * PS + 4 * d) / 4];
+                    bl[sl][d] = bLo[(2 * n2 * PS + 4 * d) / 4];
                 }
-                const m512_h8 Bh = m512_as_h8(bh[0], bh[1], bh[2], bh[3]), Bl = m512_as_h8(bl[0], bl[1], bl[2], bl[3]);
-                m512_f4 acc[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const m512_h8 ah = reinterpret_cast<const m512_h8*>(sA1 + ((n2 * 2 + t) * 2 + 0) * 1024)[lane];
-                    const m512_h8 al = reinterpret_cast<const m512_h8*>(sA1 + ((n2 * 2 + t) * 2 + 1) * 1024)[lane];
-                    const m512_f4 zero = {0.f, 0.f, 0.f, 0.f};
-                    acc[t] = m512_mma3(ah, al, Bh, Bl, zero);
+                    ah[sl][t] = reinterpret_cast<const m512_h8*>(sA1 + ((n2 * 2 + t) * 2 + 0) * 1024)[lane];
+                    al[sl][t] = reinterpret_cast<const m512_h8*>(sA1 + ((n2 * 2 + t) * 2 + 1) * 1024)[lane];
                 }
-                if (n2 > 0) {   // the previous column's results are packed while this column's products run
+            };
+            load_ops(std::integral_constant<int, 0>{});
+            auto column = [&](auto nc_) {
+                constexpr int n2 = decltype(nc_)::value;
+                constexpr int sl = n2 & 1;
+                if constexpr (n2 + 1 < 16) load_ops(std::integral_constant<int, (n2 + 1 < 16 ? n2 + 1 : 0)>{});
+                const m512_h8 Bh = m512_as_h8(bh[sl][0], bh[sl][1], bh[sl][2], bh[sl][3]);
+                const m512_h8 Bl = m512_as_h8(bl[sl][0], bl[sl][1], bl[sl][2], bl[sl][3]);
+                const m512_f4 zero = {0.f, 0.f, 0.f, 0.f};
+                const m512_f4 acc0 = m512_mma3(ah[sl][0], al[sl][0], Bh, Bl, zero);
+                const m512_f4 acc1 = m512_mma3(ah[sl][1], al[sl][1], Bh, Bl, zero);
+                if constexpr (n2 > 0) {   // the previous column's results are packed while this column's products run
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         m512_split_f16(accp[0][i], accp[1][i], Rh[(n2 - 1) >> 2][(n2 - 1) & 3][i], Rl[(n2 - 1) >> 2][(n2 - 1) & 3][i]);
                 }
-                accp[0] = acc[0];
-                accp[1] = acc[1];
-            }
+                accp[0] = acc0;
+                accp[1] = acc1;
+            };
+            m512_static_for<0, 16>(column);
 #pragma unroll
             for (int i = 0; i < 4; ++i) m512_split_f16(accp[0][i], accp[1][i], Rh[3][3][i], Rl[3][3][i]);
+#ifdef M512_STAMPS
+#pragma unroll
+            for (int a_ = 0; a_ < 4; ++a_)
+#pragma unroll
+                for (int b_ = 0; b_ < 4; ++b_)
+#pragma unroll
+                    for (int c_ = 0; c_ < 4; ++c_) { M512_PIN(Rh[a_][b_][c_]); M512_PIN(Rl[a_][b_][c_]); }
+#endif
+            M512_STAMP(2);
             // the next tile's samples travel while the rest of this tile is computed
             if (j + 1 < J) fetch(j + 1);
 
@@ -304,6 +382,15 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
                     M512_SWAP16(Rl[0][qq][i], Rl[1][qq][i]);
                     M512_SWAP16(Rl[2][qq][i], Rl[3][qq][i]);
                 }
+#ifdef M512_STAMPS
+#pragma unroll
+            for (int a_ = 0; a_ < 4; ++a_)
+#pragma unroll
+                for (int b_ = 0; b_ < 4; ++b_)
+#pragma unroll
+                    for (int c_ = 0; c_ < 4; ++c_) { M512_PIN(Rh[a_][b_][c_]); M512_PIN(Rl[a_][b_][c_]); }
+#endif
+            M512_STAMP(3);
             // now R?[sig][qq][i] in lane group gam = (re, im) of slot 4 sig + i at n2 = 4 gam + qq
 
             // ---------------------------------------------------------------- 4. stage 2, power, mel
@@ -335,24 +422,29 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
                 }
                 if constexpr ((s & 7) == 7) {
                     constexpr int h = s >> 3;
-#pragma unroll
-                    for (int ip = 0; ip < 4; ++ip) {
-                        constexpr int dummy = 0; (void)dummy;
-                        const int step = 2 * ip + h;
+                    // the blocks of steps 2 ip + h in order; the weights of block k + 1 are read while block k multiplies
+                    constexpr int NB = m512_octet_blocks<NMT>(h);
+                    m512_b8 wh[2], wl[2];
+                    auto load_w = [&](auto kc_) {
+                        constexpr int k = decltype(kc_)::value;
+                        constexpr int it = m512_octet_block<NMT>(h, k), ip = it >> 2, t = it & 3;
+                        constexpr int bi = m512_block_index<NMT>(2 * ip + h, t);
+                        wh[k & 1] = reinterpret_cast<const m512_b8*>(sW + bi * 2048)[lane];
+                        wl[k & 1] = reinterpret_cast<const m512_b8*>(sW + bi * 2048 + 1024)[lane];
+                    };
+                    load_w(std::integral_constant<int, 0>{});
+                    auto mul_w = [&](auto kc_) {
+                        constexpr int k = decltype(kc_)::value;
+                        if constexpr (k + 1 < NB) load_w(std::integral_constant<int, (k + 1 < NB ? k + 1 : 0)>{});
+                        constexpr int it = m512_octet_block<NMT>(h, k), ip = it >> 2, t = it & 3;
+                        constexpr int step = 2 * ip + h;
                         const m512_b8 ph = m512_as_b8(Ph[step][0], Ph[step][1], Ph[step][2], Ph[step][3]);
                         const m512_b8 pl = m512_as_b8(Pl[step][0], Pl[step][1], Pl[step][2], Pl[step][3]);
-#pragma unroll
-                        for (int t = 0; t < NMT; ++t) {
-                            if (m512_has_block<NMT>(step, t)) {
-                                const int bi = m512_block_index<NMT>(step, t);
-                                const m512_b8 wh = reinterpret_cast<const m512_b8*>(sW + bi * 2048)[lane];
-                                const m512_b8 wl = reinterpret_cast<const m512_b8*>(sW + bi * 2048 + 1024)[lane];
-                                eacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ph, eacc[t], 0, 0, 0);
-                                eacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, pl, eacc[t], 0, 0, 0);
-                                eacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ph, eacc[t], 0, 0, 0);
-                            }
-                        }
-                    }
+                        eacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[k & 1], ph, eacc[t], 0, 0, 0);
+                        eacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[k & 1], pl, eacc[t], 0, 0, 0);
+                        eacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[k & 1], ph, eacc[t], 0, 0, 0);
+                    };
+                    m512_static_for<0, NB>(mul_w);
                 }
             };
             auto run_slot = [&](auto sc_) {
@@ -376,6 +468,13 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
             m512_static_for<0, 16>(run_slot);
             finish_slot(std::integral_constant<int, 15>{});
 
+#ifdef M512_STAMPS
+#pragma unroll
+            for (int t_ = 0; t_ < NMT; ++t_)
+#pragma unroll
+                for (int c_ = 0; c_ < 4; ++c_) M512_PIN(eacc[t_][c_]);
+#endif
+            M512_STAMP(4);
             // ---------------------------------------------------------------- 5. log2, DCT * lifter, correction
             const float zval = P.lay.z_log2_eps + corr;
             uint32_t leh[3][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}}, lel[3][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};
@@ -402,6 +501,11 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
 #pragma unroll
             for (int i = 0; i < 4; ++i) cep[i] = fmaf(-corr, rowsum[i], cep[i]);
 
+#ifdef M512_STAMPS
+#pragma unroll
+            for (int c_ = 0; c_ < 4; ++c_) M512_PIN(cep[c_]);
+#endif
+            M512_STAMP(5);
             const int t0 = 16 * j;
             if constexpr (!ROWS) {
                 // ------------------------------------------------------------ 6a. cepstra only
@@ -413,67 +517,133 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
                 }
             } else {
                 // ------------------------------------------------------------ 6b. delta, delta-delta, rows
-                *reinterpret_cast<m512_f4*>(cring + ((t0 + n) & (M512_RING - 1)) * 16 + 4 * g) = cep;
-                const bool last = j == J - 1;
-                const int Ti = (int)T, nd = P.delta_n;
-                const float inv = P.inv_den;
-                const int dlo = j == 0 ? 0 : t0 - 2, dhi = last ? Ti : t0 + 14;
-                const int olo = j == 0 ? 0 : t0 - 4, ohi = last ? Ti : t0 + 12;
+                // cb / db: cepstra / deltas of frames t0 - 6 .. t0 + 15 in rows 0 .. 21 (rows 0..5: the previous tile's last)
+                float* const cb = cring;
+                float* const db = dring;
                 const int fo = lane & 15, cq = lane >> 4;
-                for (int f0 = dlo; f0 < dhi; f0 += 16) {           // delta of frames [dlo, dhi)
-                    const int f = f0 + fo;
-                    if (f < dhi) {
-                        m512_f4 d = {0.f, 0.f, 0.f, 0.f};
-                        for (int k = 1; k <= nd; ++k) {
-                            const int fa = min(f + k, Ti - 1), fb = max(f - k, 0);
-                            const m512_f4 a = *reinterpret_cast<const m512_f4*>(cring + (fa & (M512_RING - 1)) * 16 + 4 * cq);
-                            const m512_f4 b = *reinterpret_cast<const m512_f4*>(cring + (fb & (M512_RING - 1)) * 16 + 4 * cq);
-                            const float kf = (float)k;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) d[i] = fmaf(kf, a[i] - b[i], d[i]);
-                        }
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) d[i] *= inv;
-                        *reinterpret_cast<m512_f4*>(dring + (f & (M512_RING - 1)) * 16 + 4 * cq) = d;
-                    }
-                }
-                for (int f0 = olo; f0 < ohi; f0 += 16) {           // rows of frames [olo, ohi)
-                    const int f = f0 + fo;
-                    if (f < ohi) {
-                        m512_f4 dd = {0.f, 0.f, 0.f, 0.f};
-                        for (int k = 1; k <= nd; ++k) {
-                            const int fa = min(f + k, Ti - 1), fb = max(f - k, 0);
-                            const m512_f4 a = *reinterpret_cast<const m512_f4*>(dring + (fa & (M512_RING - 1)) * 16 + 4 * cq);
-                            const m512_f4 b = *reinterpret_cast<const m512_f4*>(dring + (fb & (M512_RING - 1)) * 16 + 4 * cq);
-                            const float kf = (float)k;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) dd[i] = fmaf(kf, a[i] - b[i], dd[i]);
-                        }
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) dd[i] *= inv;
-                        float* orow = obuf + fo * M512_OBUF_ROW + 4 * cq;
-                        *reinterpret_cast<m512_f4*>(orow) = *reinterpret_cast<const m512_f4*>(cring + (f & (M512_RING - 1)) * 16 + 4 * cq);
-                        *reinterpret_cast<m512_f4*>(orow + 16) = *reinterpret_cast<const m512_f4*>(dring + (f & (M512_RING - 1)) * 16 + 4 * cq);
-                        *reinterpret_cast<m512_f4*>(orow + 32) = dd;
-                    }
-                    // copy out: rows f0 .. f0 + nr - 1 are contiguous in memory
-                    const int nr = min(16, ohi - f0), ne = nr * 3 * C;
-                    float* dst = out + (row0 + f0) * (int64_t)(3 * C);
+                const float inv = P.inv_den;
+                *reinterpret_cast<m512_f4*>(cb + (6 + n) * 16 + 4 * g) = cep;
+                M512_LDS_FENCE();
+                const bool first = j == 0, last = j == J - 1;
+                auto copy_out = [&](int f_first, int nr) {   // rows f_first .. f_first + nr - 1 are contiguous in memory
+                    M512_LDS_FENCE();
+                    const int ne = nr * 3 * C;
+                    float* dst = out + (row0 + f_first) * (int64_t)(3 * C);
 #pragma unroll
                     for (int m = 0; m < 12; ++m) {
                         const int e = lane + 64 * m;
                         if (e < ne) dst[e] = obuf[ooff[m]];
                     }
+                };
+                if (!first && !last) {
+                    // interior tile: every frame the two windows touch lies inside the utterance, no clamps, fixed rows.
+                    // delta of frame t0 - 2 + fo (row 4 + fo)
+                    m512_f4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 1; k <= ND; ++k) {
+                        const m512_f4 a = *reinterpret_cast<const m512_f4*>(cb + (4 + k) * 16 + fo * 16 + 4 * cq);
+                        const m512_f4 bq = *reinterpret_cast<const m512_f4*>(cb + (4 - k) * 16 + fo * 16 + 4 * cq);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) d[i] = fmaf((float)k, a[i] - bq[i], d[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) d[i] *= inv;
+                    *reinterpret_cast<m512_f4*>(db + 4 * 16 + fo * 16 + 4 * cq) = d;
+                    M512_LDS_FENCE();
+                    // delta-delta of frame t0 - 4 + fo (row 2 + fo)
+                    m512_f4 dd = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 1; k <= ND; ++k) {
+                        const m512_f4 a = *reinterpret_cast<const m512_f4*>(db + (2 + k) * 16 + fo * 16 + 4 * cq);
+                        const m512_f4 bq = *reinterpret_cast<const m512_f4*>(db + (2 - k) * 16 + fo * 16 + 4 * cq);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) dd[i] = fmaf((float)k, a[i] - bq[i], dd[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dd[i] *= inv;
+                    float* orow = obuf + fo * M512_OBUF_ROW + 4 * cq;
+                    *reinterpret_cast<m512_f4*>(orow) = *reinterpret_cast<const m512_f4*>(cb + 2 * 16 + fo * 16 + 4 * cq);
+                    *reinterpret_cast<m512_f4*>(orow + 16) = *reinterpret_cast<const m512_f4*>(db + 2 * 16 + fo * 16 + 4 * cq);
+                    *reinterpret_cast<m512_f4*>(orow + 32) = dd;
+                    copy_out(t0 - 4, 16);
+                } else {
+                    // first and / or last tile of the utterance: the windows are clamped to [0, T - 1] (edge padding of
+                    // base.py:73, once for delta and once more for delta of delta)
+                    const int Ti = (int)T;
+                    const int dlo = first ? 0 : t0 - 2, dhi = last ? Ti : t0 + 14;
+                    const int olo = first ? 0 : t0 - 4, ohi = last ? Ti : t0 + 12;
+                    for (int f0 = dlo; f0 < dhi; f0 += 16) {
+                        const int f = f0 + fo;
+                        if (f < dhi) {
+                            m512_f4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int k = 1; k <= ND; ++k) {
+                                const int ra = 6 + min(f + k, Ti - 1) - t0, rb = 6 + max(f - k, 0) - t0;
+                                const m512_f4 a = *reinterpret_cast<const m512_f4*>(cb + ra * 16 + 4 * cq);
+                                const m512_f4 bq = *reinterpret_cast<const m512_f4*>(cb + rb * 16 + 4 * cq);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) d[i] = fmaf((float)k, a[i] - bq[i], d[i]);
+                            }
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) d[i] *= inv;
+                            *reinterpret_cast<m512_f4*>(db + (6 + f - t0) * 16 + 4 * cq) = d;
+                        }
+                    }
+                    M512_LDS_FENCE();
+                    for (int f0 = olo; f0 < ohi; f0 += 16) {
+                        const int f = f0 + fo;
+                        if (f < ohi) {
+                            m512_f4 dd = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int k = 1; k <= ND; ++k) {
+                                const int ra = 6 + min(f + k, Ti - 1) - t0, rb = 6 + max(f - k, 0) - t0;
+                                const m512_f4 a = *reinterpret_cast<const m512_f4*>(db + ra * 16 + 4 * cq);
+                                const m512_f4 bq = *reinterpret_cast<const m512_f4*>(db + rb * 16 + 4 * cq);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) dd[i] = fmaf((float)k, a[i] - bq[i], dd[i]);
+                            }
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) dd[i] *= inv;
+                            float* orow = obuf + fo * M512_OBUF_ROW + 4 * cq;
+                            *reinterpret_cast<m512_f4*>(orow) = *reinterpret_cast<const m512_f4*>(cb + (6 + f - t0) * 16 + 4 * cq);
+                            *reinterpret_cast<m512_f4*>(orow + 16) = *reinterpret_cast<const m512_f4*>(db + (6 + f - t0) * 16 + 4 * cq);
+                            *reinterpret_cast<m512_f4*>(orow + 32) = dd;
+                        }
+                        copy_out(f0, min(16, ohi - f0));
+                    }
+                }
+                M512_LDS_FENCE();
+                if (!last && lane < 24) {   // the next tile's history: rows 16..21 -> 0..5
+                    const int r = lane >> 2, qd = lane & 3;
+                    *reinterpret_cast<m512_f4*>(cb + r * 16 + 4 * qd) = *reinterpret_cast<const m512_f4*>(cb + (16 + r) * 16 + 4 * qd);
+                    *reinterpret_cast<m512_f4*>(db + r * 16 + 4 * qd) = *reinterpret_cast<const m512_f4*>(db + (16 + r) * 16 + 4 * qd);
                 }
                 // obuf lies over the first planes of the hi image: the rows of those planes that no staging pass
                 // rewrites (4 RQ .. PS - 1, read against zero window rows by the tile's last frames) must be finite again
+                M512_LDS_FENCE();
                 if constexpr (PS > 4 * RQ) {
                     static_assert((PS - 4 * RQ) == 8, "pad rows are one 16-byte store per plane");
                     if (lane < 16) *reinterpret_cast<m512_u4*>(imgHi + lane * PS * 2 + 4 * RQ * 2) = m512_u4{0u, 0u, 0u, 0u};
                 }
             }
+            M512_STAMP(6);
+#ifdef M512_STAMPS
+            stamp_acc_[7] += 1;
+#endif
         }
     }
+#ifdef M512_STAMPS
+    {
+        const unsigned int t1_ = m512_clock();
+        unsigned long long rt1_;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1_));
+        stamp_acc_[8] = t1_ - stamp_t0_;
+        stamp_acc_[9] = (unsigned int)(rt1_ - stamp_rt0_);
+        stamp_acc_[10] = 1;
+        if (lane == 0 && wglob < 2048)
+            for (int i = 0; i < M512_NSTAMP; ++i) atomicAdd(&m512_stamp_sum[wglob * M512_NSTAMP + i], stamp_acc_[i]);
+    }
+#endif
 }
 
 // --------------------------------------------------------------------------------------------- host side
@@ -541,14 +711,14 @@ static inline bool mfma512_applicable(const dsp_plan* p, const BatchGeom& bg, in
     return true;
 }
 
-template <int RQ, int DTYPE, int NMT, bool ROWS>
+template <int RQ, int DTYPE, int NMT, int ND>
 static int mfma512_launch_k(const M512Params& P, const void* d_wave, float* d_out, hipStream_t st) {
     constexpr int HS = 10;
     constexpr int PS = ((15 * HS + 32 > 4 * RQ ? 15 * HS + 32 : 4 * RQ) + 3) / 4 * 4;
     constexpr int WAVE_BYTES = 2 * 16 * PS * 2 + 2 * M512_RING * 16 * 4;
     const size_t lds = 65536 + (size_t)16 * 2048 + (size_t)M512_WAVES * WAVE_BYTES;
     if (lds > 163840) return 1;
-    auto kern = mfcc512m_kernel<HS, RQ, DTYPE, NMT, ROWS>;
+    auto kern = mfcc512m_kernel<HS, RQ, DTYPE, NMT, ND>;
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess)
@@ -581,16 +751,14 @@ static inline int mfma512_launch(const dsp_plan* p, const void* d_wave, int dtyp
     P.samples = bg.uniform_samples;
     P.frames = bg.uniform_frames;
     const int nmt = mp->lay.n_mtiles;
-#define M512_LAUNCH(RQ_, DT_, NMT_, ROWS_) return mfma512_launch_k<RQ_, DT_, NMT_, ROWS_>(P, d_wave, d_out, st)
-#define M512_LAUNCH_NMT(RQ_, DT_, ROWS_) \
-    do { if (nmt <= 2) M512_LAUNCH(RQ_, DT_, 2, ROWS_); else M512_LAUNCH(RQ_, DT_, 3, ROWS_); } while (0)
-#define M512_LAUNCH_DT(RQ_, ROWS_) \
-    do { if (dtype == DSP_WAVE_I16) M512_LAUNCH_NMT(RQ_, DSP_WAVE_I16, ROWS_); else M512_LAUNCH_NMT(RQ_, DSP_WAVE_F32, ROWS_); } while (0)
-    if (delta_n > 0) {
-        if (mp->rq == 44) M512_LAUNCH_DT(44, true); else M512_LAUNCH_DT(48, true);
-    } else {
-        if (mp->rq == 44) M512_LAUNCH_DT(44, false); else M512_LAUNCH_DT(48, false);
-    }
+#define M512_LAUNCH(RQ_, DT_, NMT_, ND_) return mfma512_launch_k<RQ_, DT_, NMT_, ND_>(P, d_wave, d_out, st)
+#define M512_LAUNCH_NMT(RQ_, DT_, ND_) \
+    do { if (nmt <= 2) M512_LAUNCH(RQ_, DT_, 2, ND_); else M512_LAUNCH(RQ_, DT_, 3, ND_); } while (0)
+#define M512_LAUNCH_DT(RQ_, ND_) \
+    do { if (dtype == DSP_WAVE_I16) M512_LAUNCH_NMT(RQ_, DSP_WAVE_I16, ND_); else M512_LAUNCH_NMT(RQ_, DSP_WAVE_F32, ND_); } while (0)
+#define M512_LAUNCH_ND(RQ_) \
+    do { if (delta_n == 0) M512_LAUNCH_DT(RQ_, 0); else if (delta_n == 1) M512_LAUNCH_DT(RQ_, 1); else M512_LAUNCH_DT(RQ_, 2); } while (0)
+    if (mp->rq == 44) M512_LAUNCH_ND(44); else M512_LAUNCH_ND(48);
     return 1;
 }
 #endif  // M512_KERNEL_ONLY
