@@ -56,6 +56,7 @@ struct M512Params {
     int32_t n_utt;
     int64_t samples;       // per utterance
     int64_t frames;        // per utterance
+    int32_t stagger;       // steps of 512 cycles between the start of consecutive waves of a workgroup
 };
 
 struct Mfma512Plan {
@@ -251,6 +252,10 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
     const int nw_total = gridDim.x * M512_WAVES, wglob = blockIdx.x * M512_WAVES + wv;
     const int u_lo = (int)((int64_t)P.n_utt * wglob / nw_total), u_hi = (int)((int64_t)P.n_utt * (wglob + 1) / nw_total);
 
+    // the four waves of a CU start a quarter of a tile apart: otherwise they run the LDS-heavy stage 1 in lockstep
+    // and queue on the LDS pipe while the matrix pipes idle
+    for (int w = 0; w < wv * P.stagger; ++w) __builtin_amdgcn_s_sleep(8);   // 8 x 64 cycles per step
+
     for (int utt = u_lo; utt < u_hi; ++utt) {
         const uint8_t* ubase = reinterpret_cast<const uint8_t*>(wave) + (int64_t)utt * P.samples * ESZ;
         // x[u]: u < N; prev x[u - 1]: 1 <= u <= N - 1 (u = 0 wraps to a huge offset, u >= N is out of range): both read
@@ -365,6 +370,9 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
             M512_STAMP(2);
             // the next tile's samples travel while the rest of this tile is computed
             if (j + 1 < J) fetch(j + 1);
+#ifdef M512_STAMPS
+            { const unsigned int now_ = m512_clock(); stamp_acc_[11] += now_ - stamp_prev_; }
+#endif
 
             // ---------------------------------------------------------------- 3. transpose n2-block <-> lane group
 #pragma unroll
@@ -517,60 +525,55 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
                 }
             } else {
                 // ------------------------------------------------------------ 6b. delta, delta-delta, rows
-                // cb / db: cepstra / deltas of frames t0 - 6 .. t0 + 15 in rows 0 .. 21 (rows 0..5: the previous tile's last)
+                // cb: cepstra of frames t0 - 8 .. t0 + 15 in rows 0 .. 23 (rows 0..7: the previous tile's last eight);
+                // db: deltas, same rows, used by the first / last tile of an utterance only
                 float* const cb = cring;
                 float* const db = dring;
                 const int fo = lane & 15, cq = lane >> 4;
                 const float inv = P.inv_den;
-                *reinterpret_cast<m512_f4*>(cb + (6 + n) * 16 + 4 * g) = cep;
+                *reinterpret_cast<m512_f4*>(cb + (8 + n) * 16 + 4 * g) = cep;
                 M512_LDS_FENCE();
                 const bool first = j == 0, last = j == J - 1;
                 auto copy_out = [&](int f_first, int nr) {   // rows f_first .. f_first + nr - 1 are contiguous in memory
                     M512_LDS_FENCE();
                     const int ne = nr * 3 * C;
-                    float* dst = out + (row0 + f_first) * (int64_t)(3 * C);
+                    // bounds-checked stores: elements past the block's end are dropped by the descriptor, no exec masks
+                    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(
+                        out + (row0 + f_first) * (int64_t)(3 * C), 0, ne * 4, 0x00020000);
+                    float v[12];
 #pragma unroll
-                    for (int m = 0; m < 12; ++m) {
-                        const int e = lane + 64 * m;
-                        if (e < ne) dst[e] = obuf[ooff[m]];
-                    }
+                    for (int m = 0; m < 12; ++m) v[m] = obuf[ooff[m]];
+#pragma unroll
+                    for (int m = 0; m < 12; ++m)
+                        if (64 * m < ne) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v[m]), rs_o, (lane + 64 * m) * 4, 0, 0);
                 };
                 if (!first && !last) {
-                    // interior tile: every frame the two windows touch lies inside the utterance, no clamps, fixed rows.
-                    // delta of frame t0 - 2 + fo (row 4 + fo)
-                    m512_f4 d = {0.f, 0.f, 0.f, 0.f};
+                    // interior tile: frame t0 - 4 + fo (row 4 + fo) with its whole window inside the utterance; delta of
+                    // delta written out as ONE nine-tap filter (coefficients = the delta taps convolved with themselves)
+                    m512_f4 c9[9];
 #pragma unroll
-                    for (int k = 1; k <= ND; ++k) {
-                        const m512_f4 a = *reinterpret_cast<const m512_f4*>(cb + (4 + k) * 16 + fo * 16 + 4 * cq);
-                        const m512_f4 bq = *reinterpret_cast<const m512_f4*>(cb + (4 - k) * 16 + fo * 16 + 4 * cq);
+                    for (int r = 0; r < 9; ++r) c9[r] = *reinterpret_cast<const m512_f4*>(cb + r * 16 + fo * 16 + 4 * cq);
+                    m512_f4 d, dd;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) d[i] = fmaf((float)k, a[i] - bq[i], d[i]);
+                    for (int i = 0; i < 4; ++i) {
+                        if constexpr (ND == 2) {
+                            d[i] = (c9[5][i] - c9[3][i] + 2.f * (c9[6][i] - c9[2][i])) * inv;
+                            dd[i] = (4.f * ((c9[8][i] + c9[0][i]) + (c9[7][i] + c9[1][i]) - (c9[5][i] + c9[3][i])) + (c9[6][i] + c9[2][i]) - 10.f * c9[4][i]) * (inv * inv);
+                        } else {
+                            d[i] = (c9[5][i] - c9[3][i]) * inv;
+                            dd[i] = ((c9[6][i] + c9[2][i]) - 2.f * c9[4][i]) * (inv * inv);
+                        }
                     }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) d[i] *= inv;
-                    *reinterpret_cast<m512_f4*>(db + 4 * 16 + fo * 16 + 4 * cq) = d;
-                    M512_LDS_FENCE();
-                    // delta-delta of frame t0 - 4 + fo (row 2 + fo)
-                    m512_f4 dd = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int k = 1; k <= ND; ++k) {
-                        const m512_f4 a = *reinterpret_cast<const m512_f4*>(db + (2 + k) * 16 + fo * 16 + 4 * cq);
-                        const m512_f4 bq = *reinterpret_cast<const m512_f4*>(db + (2 - k) * 16 + fo * 16 + 4 * cq);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) dd[i] = fmaf((float)k, a[i] - bq[i], dd[i]);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) dd[i] *= inv;
                     float* orow = obuf + fo * M512_OBUF_ROW + 4 * cq;
-                    *reinterpret_cast<m512_f4*>(orow) = *reinterpret_cast<const m512_f4*>(cb + 2 * 16 + fo * 16 + 4 * cq);
-                    *reinterpret_cast<m512_f4*>(orow + 16) = *reinterpret_cast<const m512_f4*>(db + 2 * 16 + fo * 16 + 4 * cq);
+                    *reinterpret_cast<m512_f4*>(orow) = c9[4];
+                    *reinterpret_cast<m512_f4*>(orow + 16) = d;
                     *reinterpret_cast<m512_f4*>(orow + 32) = dd;
                     copy_out(t0 - 4, 16);
                 } else {
                     // first and / or last tile of the utterance: the windows are clamped to [0, T - 1] (edge padding of
                     // base.py:73, once for delta and once more for delta of delta)
                     const int Ti = (int)T;
-                    const int dlo = first ? 0 : t0 - 2, dhi = last ? Ti : t0 + 14;
+                    const int dlo = first ? 0 : t0 - 6, dhi = last ? Ti : t0 + 14;
                     const int olo = first ? 0 : t0 - 4, ohi = last ? Ti : t0 + 12;
                     for (int f0 = dlo; f0 < dhi; f0 += 16) {
                         const int f = f0 + fo;
@@ -578,7 +581,7 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
                             m512_f4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                             for (int k = 1; k <= ND; ++k) {
-                                const int ra = 6 + min(f + k, Ti - 1) - t0, rb = 6 + max(f - k, 0) - t0;
+                                const int ra = 8 + min(f + k, Ti - 1) - t0, rb = 8 + max(f - k, 0) - t0;
                                 const m512_f4 a = *reinterpret_cast<const m512_f4*>(cb + ra * 16 + 4 * cq);
                                 const m512_f4 bq = *reinterpret_cast<const m512_f4*>(cb + rb * 16 + 4 * cq);
 #pragma unroll
@@ -586,7 +589,7 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
                             }
 #pragma unroll
                             for (int i = 0; i < 4; ++i) d[i] *= inv;
-                            *reinterpret_cast<m512_f4*>(db + (6 + f - t0) * 16 + 4 * cq) = d;
+                            *reinterpret_cast<m512_f4*>(db + (8 + f - t0) * 16 + 4 * cq) = d;
                         }
                     }
                     M512_LDS_FENCE();
@@ -596,7 +599,7 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
                             m512_f4 dd = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                             for (int k = 1; k <= ND; ++k) {
-                                const int ra = 6 + min(f + k, Ti - 1) - t0, rb = 6 + max(f - k, 0) - t0;
+                                const int ra = 8 + min(f + k, Ti - 1) - t0, rb = 8 + max(f - k, 0) - t0;
                                 const m512_f4 a = *reinterpret_cast<const m512_f4*>(db + ra * 16 + 4 * cq);
                                 const m512_f4 bq = *reinterpret_cast<const m512_f4*>(db + rb * 16 + 4 * cq);
 #pragma unroll
@@ -605,18 +608,17 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
 #pragma unroll
                             for (int i = 0; i < 4; ++i) dd[i] *= inv;
                             float* orow = obuf + fo * M512_OBUF_ROW + 4 * cq;
-                            *reinterpret_cast<m512_f4*>(orow) = *reinterpret_cast<const m512_f4*>(cb + (6 + f - t0) * 16 + 4 * cq);
-                            *reinterpret_cast<m512_f4*>(orow + 16) = *reinterpret_cast<const m512_f4*>(db + (6 + f - t0) * 16 + 4 * cq);
+                            *reinterpret_cast<m512_f4*>(orow) = *reinterpret_cast<const m512_f4*>(cb + (8 + f - t0) * 16 + 4 * cq);
+                            *reinterpret_cast<m512_f4*>(orow + 16) = *reinterpret_cast<const m512_f4*>(db + (8 + f - t0) * 16 + 4 * cq);
                             *reinterpret_cast<m512_f4*>(orow + 32) = dd;
                         }
                         copy_out(f0, min(16, ohi - f0));
                     }
                 }
                 M512_LDS_FENCE();
-                if (!last && lane < 24) {   // the next tile's history: rows 16..21 -> 0..5
+                if (!last && lane < 32) {   // the next tile's history: rows 16..23 -> 0..7
                     const int r = lane >> 2, qd = lane & 3;
                     *reinterpret_cast<m512_f4*>(cb + r * 16 + 4 * qd) = *reinterpret_cast<const m512_f4*>(cb + (16 + r) * 16 + 4 * qd);
-                    *reinterpret_cast<m512_f4*>(db + r * 16 + 4 * qd) = *reinterpret_cast<const m512_f4*>(db + (16 + r) * 16 + 4 * qd);
                 }
                 // obuf lies over the first planes of the hi image: the rows of those planes that no staging pass
                 // rewrites (4 RQ .. PS - 1, read against zero window rows by the tile's last frames) must be finite again
@@ -750,6 +752,11 @@ static inline int mfma512_launch(const dsp_plan* p, const void* d_wave, int dtyp
     P.n_utt = bg.n_utt;
     P.samples = bg.uniform_samples;
     P.frames = bg.uniform_frames;
+    {
+        static int stg = -1;
+        if (stg < 0) { const char* e = getenv("DSP_M512_STAGGER"); stg = e ? atoi(e) : 4; }
+        P.stagger = stg;
+    }
     const int nmt = mp->lay.n_mtiles;
 #define M512_LAUNCH(RQ_, DT_, NMT_, ND_) return mfma512_launch_k<RQ_, DT_, NMT_, ND_>(P, d_wave, d_out, st)
 #define M512_LAUNCH_NMT(RQ_, DT_, ND_) \

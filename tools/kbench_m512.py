@@ -46,6 +46,7 @@ def main():
     tot = sum(buf[i] for i in range(7))
     for i in range(7):
         print(f'  {names[i] if i < 1 else names[i]:26s} {buf[i] / tiles:8.0f} cycles/tile  {100.0 * buf[i] / tot:5.1f} %')
+    print(f'  (of which: issue of the next tile\'s loads {buf[11] / tiles:8.0f})')
     nw = buf[10]
     print(f'  per tile {tot / tiles:8.0f}; tiles per launch {tiles / R:.0f}; waves {nw / R:.0f}; wave lifetime {buf[8] / nw:9.0f} cycles '
           f'= {buf[9] / nw * 0.01:7.2f} us; shader clock {buf[8] / max(buf[9], 1) * 0.1:5.2f} GHz')
