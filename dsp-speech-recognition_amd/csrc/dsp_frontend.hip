@@ -157,6 +157,13 @@ int dsp_debug_force_generic(int on) {
     return DSP_OK;
 }
 
+int dsp_debug_use_mfma512(int on) {
+    g_use_mfma512 = on < 0 ? -1 : (on ? 1 : 0);
+    return DSP_OK;
+}
+
+int dsp_plan_has_mfma512(const dsp_plan* plan) { return plan && plan->d_mfma ? 1 : 0; }
+
 int dsp_debug_pool_stats(long long* n_buffers, long long* bytes) {
     dsp_workspace_pool().stats(n_buffers, bytes);
     return DSP_OK;

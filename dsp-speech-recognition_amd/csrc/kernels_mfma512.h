@@ -37,13 +37,14 @@ typedef _Float16 m512_h2 __attribute__((ext_vector_type(2)));
 typedef float m512_f2 __attribute__((ext_vector_type(2)));
 typedef __bf16 m512_b2 __attribute__((ext_vector_type(2)));
 
-#define M512_WAVES 4
+#define M512_WAVES 8
+#ifndef M512_FETCH_SLOT
+#define M512_FETCH_SLOT 11   // stage-2 slot after which the next tile's samples are requested
+#endif
 // Lanes of a wave hand data to each other through LDS (the LDS queue of a wave is in order).  hipcc reasons per
 // lane: a load whose address it can prove different from an earlier store's IN THE SAME LANE may be hoisted above
 // that store -- this keeps program order at the hand-over points.
 #define M512_LDS_FENCE() asm volatile("" ::: "memory")
-#define M512_RING 32          // frames in the cepstra / delta rings
-#define M512_OBUF_ROW 48      // floats per row of the output staging buffer: 3 x 16
 
 struct M512Params {
     const uint8_t* tables;
@@ -57,12 +58,12 @@ struct M512Params {
     int64_t samples;       // per utterance
     int64_t frames;        // per utterance
     int32_t stagger;       // steps of 512 cycles between the start of consecutive waves of a workgroup
+    int32_t splits;        // work items per utterance (row ranges of equal size): > 1 when the batch has fewer utterances than waves
 };
 
 struct Mfma512Plan {
     uint8_t* d_tables;
     M512Layout lay;
-    int rq;                // staging rows per lane quarter (template instantiation)
 };
 
 __device__ __forceinline__ void m512_split_f16(float a, float b, uint32_t& hi, uint32_t& lo) {
@@ -129,13 +130,35 @@ __device__ __forceinline__ float m512_buf_load(__amdgpu_buffer_rsrc_t rs, int32_
     }
 }
 
+// Eight consecutive samples as floats (two 16-byte loads of fp32, one of int16), bounds-checked per dword.
+template <int DTYPE>
+__device__ __forceinline__ void m512_buf_load8(__amdgpu_buffer_rsrc_t rs, uint32_t voff, float* dst) {
+    if constexpr (DTYPE == DSP_WAVE_I16) {
+        const m512_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int32_t)voff, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            dst[2 * k] = (float)(int16_t)(v[k] & 0xffffu);
+            dst[2 * k + 1] = (float)(int16_t)(v[k] >> 16);
+        }
+    } else {
+        // (whole-vector casts: an element-wise bit_cast of the builtin's result makes hipcc 7.2 narrow the load to one dword)
+        const m512_f4 a = __builtin_bit_cast(m512_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int32_t)voff, 0, 0));
+        const m512_f4 b = __builtin_bit_cast(m512_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int32_t)(voff + 16u), 0, 0));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            dst[k] = a[k];
+            dst[4 + k] = b[k];
+        }
+    }
+}
+
 // Which mel blocks exist is a compile-time pattern (a run-time test per block costs register copies at every join):
 // two row tiles: all 16 blocks; three row tiles: tile 1 (which carries the energy row) in every step, tile 0 only for
-// the lower half of the spectrum (steps 0..3), tile 2 only for the upper half (steps 4..7): 16 blocks.  The table
+// the lowest quarter of the spectrum (steps 0, 1), tile 2 only for the upper half (steps 4..7): 14 blocks.  The table
 // builder refuses a filterbank with weight outside the pattern (mfma512_tables.h).
 template <int NMT>
 __host__ __device__ constexpr bool m512_has_block(int step, int tile) {
-    return NMT <= 2 ? true : (tile == 1 || (tile == 0 && step < 4) || (tile == 2 && step >= 4));
+    return NMT <= 2 ? true : (tile == 1 || (tile == 0 && step < 2) || (tile == 2 && step >= 4));
 }
 template <int NMT>
 __host__ __device__ constexpr int m512_block_index(int step, int tile) {
@@ -169,79 +192,105 @@ __host__ __device__ constexpr int m512_octet_block(int h, int k) {   // -> ip * 
     return 0;
 }
 
-// HS: hop in rows of 16 samples; RQ: staging rows per lane quarter (4 RQ >= 15 HS + ceil(L / 16), RQ % 4 == 0);
-// PS: plane stride in halfs (>= 15 HS + 32 and >= 4 RQ, multiple of 4).
-template <int HS, int RQ, int DTYPE, int NMT, int ND>
-__global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params P, const void* __restrict__ wave,
-                                                                      float* __restrict__ out) {
-    constexpr int PS = ((15 * HS + 32 > 4 * RQ ? 15 * HS + 32 : 4 * RQ) + 3) / 4 * 4;
-    constexpr int IMG_BYTES = 16 * PS * 2;
-    constexpr int WAVE_BYTES = 2 * IMG_BYTES + 2 * M512_RING * 16 * 4;
+// HS: hop in rows of 16 samples (10 for a 160-sample hop).  WAVES: 8 (two per SIMD, 256 registers each) or 4.
+// The image of a tile holds 8 of the 16 sample planes at a time (n2 = 0..7, then 8..15), rows 0..191.
+template <int HS, int DTYPE, int NMT, int ND, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void mfcc512m_kernel(M512Params P, const void* __restrict__ wave,
+                                                                          float* __restrict__ out) {
+    constexpr int PS = 192;                       // rows per plane (15 HS + 32 <= 192)
+    static_assert(15 * HS + 32 <= PS, "hop too long for the image");
+    constexpr int IMG_BYTES = 8 * PS * 2;         // one half (8 planes) of fp16
+    constexpr int CB_ROWS = 24;
+    constexpr int WAVE_BYTES = 2 * IMG_BYTES + CB_ROWS * 64;
     constexpr int ESZ = DTYPE == DSP_WAVE_I16 ? 2 : 4;
-    constexpr bool ROWS = ND > 0;   // ND: delta window (base.py:70-79), 0 = cepstra only
+    constexpr bool ROWS = ND > 0;                 // ND: delta window (base.py:70-79), 0 = cepstra only
+    constexpr int NWB = m512_octet_blocks<NMT>(0) + m512_octet_blocks<NMT>(1);
     extern __shared__ __attribute__((aligned(16))) uint8_t m512_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int nwb = 16;   // mel blocks of the pattern (m512_has_block)
     uint8_t* const sA1 = m512_smem;
     uint8_t* const sW = m512_smem + 65536;
-    uint8_t* const sWave = m512_smem + 65536 + nwb * 2048 + wv * WAVE_BYTES;
+    uint8_t* const sWave = m512_smem + 65536 + NWB * 2048 + wv * WAVE_BYTES;
     uint8_t* const imgHi = sWave;
     uint8_t* const imgLo = sWave + IMG_BYTES;
-    float* const cring = reinterpret_cast<float*>(sWave + 2 * IMG_BYTES);
-    float* const dring = cring + M512_RING * 16;
-    float* const obuf = reinterpret_cast<float*>(imgHi);   // dead between stage 1 and the next staging
+    float* const cb = reinterpret_cast<float*>(sWave + 2 * IMG_BYTES);   // cepstra of frames t0 - 8 .. t0 + 15
+    float* const db = reinterpret_cast<float*>(imgHi);                    // deltas (edge tiles only): over the image,
+                                                                          // dead between stage 1 and the next staging
+    const int g = lane >> 4, n = lane & 15;
+    const int C = P.C;
+    const int T = (int)P.frames;
+    const int splits = P.splits;
 
-    // ---- tables -> LDS (A1, mel blocks), whole image zeroed (rows no staging pass writes must be finite)
+    // ---- this wave's work items: (utterance, part) -> rows [o_lo, o_hi) of the utterance
+    const int nw_total = gridDim.x * WAVES, wglob = blockIdx.x * WAVES + wv;
+    const int64_t n_items = (int64_t)P.n_utt * splits;
+    const int it_lo = (int)(n_items * wglob / nw_total), it_hi = (int)(n_items * (wglob + 1) / nw_total);
+
+    // raw samples of one tile: half h (planes 8 h .. 8 h + 7): rows 2 l, 2 l + 1 (xa) and row 128 + l (xb) of the lane
+    float xa[2][16], xb[2][8], pa[2][2], pb[2];
+    __amdgpu_buffer_rsrc_t rs_x, rs_p;
+    auto fetch = [&](int t0s) {   // t0s: first frame of the tile
+        // the whole offset travels in the VGPR / immediate (the descriptor's range check covers those two only)
+        const uint32_t base = (uint32_t)(t0s * P.S) * (uint32_t)ESZ;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t oa = base + (uint32_t)((32 * lane + 8 * h) * ESZ), ob = base + (uint32_t)((16 * (128 + lane) + 8 * h) * ESZ);
+            m512_buf_load8<DTYPE>(rs_x, oa, &xa[h][0]);
+            m512_buf_load8<DTYPE>(rs_x, oa + (uint32_t)(16 * ESZ), &xa[h][8]);
+            m512_buf_load8<DTYPE>(rs_x, ob, &xb[h][0]);
+            pa[h][0] = m512_buf_load<DTYPE>(rs_p, (int32_t)(oa - (uint32_t)ESZ), 0);   // sample 0 of the utterance wraps: reads 0
+            pa[h][1] = m512_buf_load<DTYPE>(rs_p, (int32_t)(oa + (uint32_t)(15 * ESZ)), 0);
+            pb[h] = m512_buf_load<DTYPE>(rs_p, (int32_t)(ob - (uint32_t)ESZ), 0);
+        }
+    };
+    auto open_item = [&](int item, int& utt, int& o_lo, int& o_hi, int& c_lo, int& J) {
+        utt = item / splits;
+        const int part = item - utt * splits;
+        o_lo = (int)((int64_t)T * part / splits);
+        o_hi = (int)((int64_t)T * (part + 1) / splits);
+        c_lo = o_lo >= 8 ? o_lo - 8 : 0;                        // eight frames of history for the delta windows
+        const int c_hi = o_hi + 4 < T ? o_hi + 4 : T;
+        J = (c_hi - c_lo + 15) >> 4;
+        const uint8_t* ubase = reinterpret_cast<const uint8_t*>(wave) + (int64_t)utt * P.samples * ESZ;
+        // x[u]: u < N; x[u - 1] through rs_p: 1 <= u <= N - 1.  Outside both read as zero: y[0] = x[0], and a zero tail
+        // AFTER pre-emphasis (sigproc.py:79-91 pads y, not x)
+        rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(ubase), 0, (int32_t)(P.samples * ESZ), 0x00020000);
+        rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(ubase), 0, (int32_t)((P.samples - 1) * ESZ), 0x00020000);
+    };
+    int utt = 0, o_lo = 0, o_hi = 0, c_lo = 0, J = 0;
+
+    // ---- tables -> LDS (A1, mel blocks); image zeroed once (every row is rewritten by every staging pass)
     {
         const m512_u4* src = reinterpret_cast<const m512_u4*>(P.tables + P.lay.off_a1);
         m512_u4* dst = reinterpret_cast<m512_u4*>(sA1);
-        for (int i = tid; i < 65536 / 16; i += 64 * M512_WAVES) dst[i] = src[i];
+        for (int i = tid; i < 65536 / 16; i += 64 * WAVES) dst[i] = src[i];
         const m512_u4* srcw = reinterpret_cast<const m512_u4*>(P.tables + P.lay.off_w);
         m512_u4* dstw = reinterpret_cast<m512_u4*>(sW);
-        for (int i = tid; i < nwb * 128; i += 64 * M512_WAVES) dstw[i] = srcw[i];
+        for (int i = tid; i < NWB * 128; i += 64 * WAVES) dstw[i] = srcw[i];
         m512_u4* z = reinterpret_cast<m512_u4*>(sWave);
         const m512_u4 zero = {0, 0, 0, 0};
         for (int i = lane; i < WAVE_BYTES / 16; i += 64) z[i] = zero;
     }
-    // ---- register-resident operands: stage-2 matrices, DCT, row sums
-    const int g = lane >> 4, n = lane & 15;
-    m512_h8 a2[2][2], a2p[2][2], dmt[2][2];
+    // ---- register-resident: the stage-2 matrix of DFT rows 1..15 and the row sums of the DCT
+    m512_h8 a2[2][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int hl = 0; hl < 2; ++hl) {
+        for (int hl = 0; hl < 2; ++hl)
             a2[u][hl] = reinterpret_cast<const m512_h8*>(P.tables + P.lay.off_a2 + (u * 2 + hl) * 1024)[lane];
-            a2p[u][hl] = reinterpret_cast<const m512_h8*>(P.tables + P.lay.off_a2p + (u * 2 + hl) * 1024)[lane];
-            dmt[u][hl] = reinterpret_cast<const m512_h8*>(P.tables + P.lay.off_dm + (u * 2 + hl) * 1024)[lane];
-        }
     float rowsum[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) rowsum[i] = reinterpret_cast<const float*>(P.tables + P.lay.off_rowsum)[4 * g + i];
     __syncthreads();
 
-    // lane constants
-    const int q = lane >> 4, p = lane & 15;                          // staging: plane p, rows RQ q + i
-    const int32_t st_goff = (16 * RQ * q + p) * ESZ;                  // byte offset of the lane's first sample in a tile
-    const uint32_t st_loff = 2u * (uint32_t)(p * PS + RQ * q);        // ... and of its first half in a plane image
-    const uint32_t b_loff = 2u * (uint32_t)(HS * n + 8 * g);          // stage 1: the lane's K octet in plane 0
     // the lane's K octet of plane 0 as LDS pointers: constant offsets fold into the ds_read_b32's offset field, and
     // volatile keeps hipcc from pairing neighbours into ds_read2_b32 (twice the LDS cycles per byte; the octet starts
     // at a 4-byte boundary only, so wider reads are not available)
     typedef __attribute__((address_space(3))) const volatile uint32_t* lds_cvu32;
+    const uint32_t b_loff = 2u * (uint32_t)(HS * n + 8 * g);
     const lds_cvu32 bHi = reinterpret_cast<lds_cvu32>((uint32_t)reinterpret_cast<uintptr_t>(imgHi + b_loff));
     const lds_cvu32 bLo = reinterpret_cast<lds_cvu32>((uint32_t)reinterpret_cast<uintptr_t>(imgLo + b_loff));
     const float cpre = P.preemph;
-    const int C = P.C;
-    const int64_t T = P.frames;
-    const int J = (int)((T + 15) >> 4);
-
-    int ooff[12];   // copy-out: element lane + 64 m of a 16-row block of [x | d | dd] rows -> its float in obuf
-#pragma unroll
-    for (int m = 0; m < 12; ++m) {
-        const int e = lane + 64 * m, W3 = 3 * C, fr = e / W3, col = e - fr * W3, part = col / C, cc = col - part * C;
-        ooff[m] = fr < 16 ? fr * M512_OBUF_ROW + part * 16 + cc : 0;
-    }
 
 #ifdef M512_STAMPS
     unsigned int stamp_acc_[M512_NSTAMP] = {0}, stamp_prev_ = m512_clock();
@@ -249,43 +298,35 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
     unsigned long long stamp_rt0_;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_rt0_));
 #endif
-    const int nw_total = gridDim.x * M512_WAVES, wglob = blockIdx.x * M512_WAVES + wv;
-    const int u_lo = (int)((int64_t)P.n_utt * wglob / nw_total), u_hi = (int)((int64_t)P.n_utt * (wglob + 1) / nw_total);
-
-    // the four waves of a CU start a quarter of a tile apart: otherwise they run the LDS-heavy stage 1 in lockstep
-    // and queue on the LDS pipe while the matrix pipes idle
+    // the waves of a SIMD pair / of a CU start apart, so that they do not run the LDS-heavy stage 1 in lockstep
     for (int w = 0; w < wv * P.stagger; ++w) __builtin_amdgcn_s_sleep(8);   // 8 x 64 cycles per step
 
-    for (int utt = u_lo; utt < u_hi; ++utt) {
-        const uint8_t* ubase = reinterpret_cast<const uint8_t*>(wave) + (int64_t)utt * P.samples * ESZ;
-        // x[u]: u < N; prev x[u - 1]: 1 <= u <= N - 1 (u = 0 wraps to a huge offset, u >= N is out of range): both read
-        // as zero outside, which gives y[0] = x[0] and a zero tail AFTER pre-emphasis (sigproc.py:79-91 pads y, not x)
-        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(ubase), 0, (int32_t)(P.samples * ESZ), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(ubase), 0, (int32_t)((P.samples - 1) * ESZ), 0x00020000);
+    for (int item = it_lo; item < it_hi; ++item) {
+        open_item(item, utt, o_lo, o_hi, c_lo, J);
         const int64_t row0 = (int64_t)utt * T;                        // first output row of the utterance
-
-        float xs[RQ], xp[RQ];
-        auto fetch = [&](int j) {
-            // the whole offset travels in the VGPR / immediate (the descriptor's range check covers those two only);
-            // unsigned sums, so hipcc folds the constants into the instruction's offset field
-            const uint32_t voff = (uint32_t)st_goff + (uint32_t)(j * 16 * P.S * ESZ);
-            const uint32_t voffp = voff + (uint32_t)(16 * ESZ - ESZ);     // x[u - 1] of row i >= 1: never negative
-            xs[0] = m512_buf_load<DTYPE>(rs_x, (int32_t)voff, 0);
-            xp[0] = m512_buf_load<DTYPE>(rs_p, (int32_t)(voff - (uint32_t)ESZ), 0);   // u = 0 wraps: out of range, reads 0
-#pragma unroll
-            for (int i = 1; i < RQ; ++i) {
-                xs[i] = m512_buf_load<DTYPE>(rs_x, (int32_t)(voff + (uint32_t)(16 * ESZ * i)), 0);
-                xp[i] = m512_buf_load<DTYPE>(rs_p, (int32_t)(voffp + (uint32_t)(16 * ESZ * (i - 1))), 0);
-            }
-        };
-        fetch(0);
+        // rows [o_lo, o_hi) of the utterance through a descriptor: stores outside are dropped (a negative offset wraps)
+        const int Wd = ROWS ? 3 * C : (int)P.ld_out;
+        const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(out + (row0 + o_lo) * (int64_t)Wd, 0,
+                                                                               (int32_t)((o_hi - o_lo) * Wd * 4), 0x00020000);
+        const int Nsamp = (int)P.samples;
 
         for (int j = 0; j < J; ++j) {
-            M512_STAMP(0);   // loop overhead / fetch of the first tile
-            // ---------------------------------------------------------------- 1. staging
-            float mx = fabsf(xp[0]);
+            const int t0 = c_lo + 16 * j;
+            // Two waves per SIMD (256 registers each): the 54 registers of a tile's raw samples cannot stay live through
+            // stage 2, so every tile requests its samples here and the other wave of the SIMD computes meanwhile (any
+            // later request point spills, and a spill reload waits for the outstanding sample loads).  One wave per
+            // SIMD (512 registers): the next tile's samples are requested right after stage 1, below.
+            if (WAVES == 8 || j == 0) fetch(t0);
+            M512_STAMP(0);
+            // ---------------------------------------------------------------- 1. scale of the tile
+            float mx = fmaxf(fabsf(pa[0][0]), fabsf(pa[1][0]));
 #pragma unroll
-            for (int i = 0; i < RQ; i += 2) asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mx) : "v"(xs[i]), "v"(xs[i + 1]));
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mx) : "v"(xa[h][e]), "v"(xa[h][e + 1]));
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mx) : "v"(xb[h][e]), "v"(xb[h][e + 1]));
+            }
             // wave maximum of non-negative floats = maximum of their bit patterns: four DPP steps inside each row of 16
             // lanes, then the four rows on the scalar side
             uint32_t mu = __builtin_bit_cast(uint32_t, mx);
@@ -304,33 +345,60 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
             const float sc = __builtin_bit_cast(float, (uint32_t)(esc + 127) << 23);
             const float csc = -cpre * sc;
             const float corr = (float)(2 * esc + M512_WSH);
-#pragma unroll
-            for (int i = 0; i < RQ; i += 4) {
-                uint32_t h0, l0, h1, l1;
-                const float y0 = fmaf(xp[i], csc, xs[i] * sc), y1 = fmaf(xp[i + 1], csc, xs[i + 1] * sc);
-                const float y2 = fmaf(xp[i + 2], csc, xs[i + 2] * sc), y3 = fmaf(xp[i + 3], csc, xs[i + 3] * sc);
-                m512_split_f16(y0, y1, h0, l0);
-                m512_split_f16(y2, y3, h1, l1);
-                *reinterpret_cast<uint2*>(imgHi + st_loff + 2 * i) = make_uint2(h0, h1);
-                *reinterpret_cast<uint2*>(imgLo + st_loff + 2 * i) = make_uint2(l0, l1);
-            }
+            // the sample at index N (the first one past the utterance) has a predecessor but must be zero: tiles that
+            // reach the end of the utterance clear it
+            const bool has_end = t0 * P.S + 16 * PS > Nsamp;
 
-            M512_LDS_FENCE();
-            M512_STAMP(1);
-            // ---------------------------------------------------------------- 2. stage 1
+            // ---------------------------------------------------------------- 2. staging + stage 1, half by half
             uint32_t Rh[4][4][4], Rl[4][4][4];                        // [n2 >> 2][n2 & 3][i]: (re, im) of row 4 g + i
             m512_f4 accp[2];
-            // the operands of column n2 + 1 are read while the products of column n2 run (one wave per SIMD: nobody
-            // else hides the LDS latency)
             uint32_t bh[2][4], bl[2][4];
             m512_h8 ah[2][2], al[2][2];
+            auto stage_half = [&](auto hc_) {
+                constexpr int h = decltype(hc_)::value;
+                // rows 2 l and 2 l + 1: the two rows of a plane share a dword
+                float ya[16], yb[8];
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        ya[8 * r2 + e] = fmaf(e == 0 ? pa[h][r2] : xa[h][8 * r2 + e - 1], csc, xa[h][8 * r2 + e] * sc);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) yb[e] = fmaf(e == 0 ? pb[h] : xb[h][e - 1], csc, xb[h][e] * sc);
+                if (has_end) {
+                    const int da = Nsamp - (t0 * P.S + 32 * lane + 8 * h), dbb = Nsamp - (t0 * P.S + 16 * (128 + lane) + 8 * h);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if (da == e) ya[e] = 0.f;
+                        if (da == 16 + e) ya[8 + e] = 0.f;
+                        if (dbb == e) yb[e] = 0.f;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    uint32_t hh, ll;
+                    m512_split_f16(ya[e], ya[8 + e], hh, ll);
+                    *reinterpret_cast<uint32_t*>(imgHi + 2 * (e * PS) + 4 * lane) = hh;
+                    *reinterpret_cast<uint32_t*>(imgLo + 2 * (e * PS) + 4 * lane) = ll;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    uint32_t hh, ll;
+                    m512_split_f16(yb[e], yb[e + 1], hh, ll);
+                    *reinterpret_cast<uint16_t*>(imgHi + 2 * (e * PS + 128) + 2 * lane) = (uint16_t)hh;
+                    *reinterpret_cast<uint16_t*>(imgHi + 2 * ((e + 1) * PS + 128) + 2 * lane) = (uint16_t)(hh >> 16);
+                    *reinterpret_cast<uint16_t*>(imgLo + 2 * (e * PS + 128) + 2 * lane) = (uint16_t)ll;
+                    *reinterpret_cast<uint16_t*>(imgLo + 2 * ((e + 1) * PS + 128) + 2 * lane) = (uint16_t)(ll >> 16);
+                }
+            };
+            // the operands of column n2 + 1 are read while the products of column n2 run
             auto load_ops = [&](auto nc_) {
                 constexpr int n2 = decltype(nc_)::value;
-                constexpr int sl = n2 & 1;
+                constexpr int sl = n2 & 1, pl = n2 & 7;
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    bh[sl][d] = bHi[(2 * n2 * PS + 4 * d) / 4];
-                    bl[sl][d] = bLo[(2 * n2 * PS + 4 * d) / 4];
+                    bh[sl][d] = bHi[(2 * pl * PS + 4 * d) / 4];
+                    bl[sl][d] = bLo[(2 * pl * PS + 4 * d) / 4];
                 }
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
@@ -338,11 +406,10 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
                     al[sl][t] = reinterpret_cast<const m512_h8*>(sA1 + ((n2 * 2 + t) * 2 + 1) * 1024)[lane];
                 }
             };
-            load_ops(std::integral_constant<int, 0>{});
             auto column = [&](auto nc_) {
                 constexpr int n2 = decltype(nc_)::value;
                 constexpr int sl = n2 & 1;
-                if constexpr (n2 + 1 < 16) load_ops(std::integral_constant<int, (n2 + 1 < 16 ? n2 + 1 : 0)>{});
+                if constexpr ((n2 & 7) != 7) load_ops(std::integral_constant<int, ((n2 & 7) != 7 ? n2 + 1 : 0)>{});
                 const m512_h8 Bh = m512_as_h8(bh[sl][0], bh[sl][1], bh[sl][2], bh[sl][3]);
                 const m512_h8 Bl = m512_as_h8(bl[sl][0], bl[sl][1], bl[sl][2], bl[sl][3]);
                 const m512_f4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -356,9 +423,19 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
                 accp[0] = acc0;
                 accp[1] = acc1;
             };
-            m512_static_for<0, 16>(column);
+            stage_half(std::integral_constant<int, 0>{});
+            M512_LDS_FENCE();
+            M512_STAMP(1);
+            load_ops(std::integral_constant<int, 0>{});
+            m512_static_for<0, 8>(column);
+            M512_LDS_FENCE();
+            stage_half(std::integral_constant<int, 1>{});
+            M512_LDS_FENCE();
+            load_ops(std::integral_constant<int, 8>{});
+            m512_static_for<8, 16>(column);
 #pragma unroll
             for (int i = 0; i < 4; ++i) m512_split_f16(accp[0][i], accp[1][i], Rh[3][3][i], Rl[3][3][i]);
+            M512_LDS_FENCE();
 #ifdef M512_STAMPS
 #pragma unroll
             for (int a_ = 0; a_ < 4; ++a_)
@@ -368,11 +445,9 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
                     for (int c_ = 0; c_ < 4; ++c_) { M512_PIN(Rh[a_][b_][c_]); M512_PIN(Rl[a_][b_][c_]); }
 #endif
             M512_STAMP(2);
-            // the next tile's samples travel while the rest of this tile is computed
-            if (j + 1 < J) fetch(j + 1);
-#ifdef M512_STAMPS
-            { const unsigned int now_ = m512_clock(); stamp_acc_[11] += now_ - stamp_prev_; }
-#endif
+            if constexpr (WAVES == 4) {
+                if (j + 1 < J) fetch(t0 + 16);
+            }
 
             // ---------------------------------------------------------------- 3. transpose n2-block <-> lane group
 #pragma unroll
@@ -455,6 +530,13 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
                     m512_static_for<0, NB>(mul_w);
                 }
             };
+            // slot 0 (DFT rows 0 and 16) has its own matrix, read from memory (L2) for this one use
+            m512_h8 a2p[2][2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl)
+                    a2p[u][hl] = reinterpret_cast<const m512_h8*>(P.tables + P.lay.off_a2p + (u * 2 + hl) * 1024)[lane];
             auto run_slot = [&](auto sc_) {
                 constexpr int s = decltype(sc_)::value;
                 constexpr int sig = s >> 2, i = s & 3;
@@ -475,7 +557,6 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
             };
             m512_static_for<0, 16>(run_slot);
             finish_slot(std::integral_constant<int, 15>{});
-
 #ifdef M512_STAMPS
 #pragma unroll
             for (int t_ = 0; t_ < NMT; ++t_)
@@ -483,7 +564,14 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
                 for (int c_ = 0; c_ < 4; ++c_) M512_PIN(eacc[t_][c_]);
 #endif
             M512_STAMP(4);
+
             // ---------------------------------------------------------------- 5. log2, DCT * lifter, correction
+            m512_h8 dmt[2][2];
+#pragma unroll
+            for (int u = 0; u < (NMT > 2 ? 2 : 1); ++u)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl)
+                    dmt[u][hl] = reinterpret_cast<const m512_h8*>(P.tables + P.lay.off_dm + (u * 2 + hl) * 1024)[lane];
             const float zval = P.lay.z_log2_eps + corr;
             uint32_t leh[3][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}}, lel[3][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};
 #pragma unroll
@@ -504,49 +592,39 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
             m512_f4 cep = {0.f, 0.f, 0.f, 0.f};
             cep = m512_mma3(dmt[0][0], dmt[0][1], m512_as_h8(leh[0][0], leh[0][1], leh[1][0], leh[1][1]),
                             m512_as_h8(lel[0][0], lel[0][1], lel[1][0], lel[1][1]), cep);
-            if (NMT > 2)
+            if constexpr (NMT > 2)
                 cep = m512_mma3(dmt[1][0], dmt[1][1], m512_as_h8(leh[2][0], leh[2][1], 0u, 0u), m512_as_h8(lel[2][0], lel[2][1], 0u, 0u), cep);
 #pragma unroll
             for (int i = 0; i < 4; ++i) cep[i] = fmaf(-corr, rowsum[i], cep[i]);
-
 #ifdef M512_STAMPS
 #pragma unroll
             for (int c_ = 0; c_ < 4; ++c_) M512_PIN(cep[c_]);
 #endif
             M512_STAMP(5);
-            const int t0 = 16 * j;
+
+            // one quad of a row: coefficients 4 cq .. 4 cq + 3 of part `part` (0 x, 1 delta, 2 delta-delta) of frame f
+            auto store_quad = [&](int f, int cq, int part, m512_f4 v) {
+                const int col = 4 * cq;
+                const int32_t off = ((f - o_lo) * Wd + part * C + col) * 4;
+                if (col + 3 < C) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(m512_u4, v), rs_o, off, 0, 0);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        if (col + i < C) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v[i]), rs_o, off + 4 * i, 0, 0);
+                }
+            };
             if constexpr (!ROWS) {
                 // ------------------------------------------------------------ 6a. cepstra only
-                if (t0 + n < T) {
-                    float* o = out + (row0 + t0 + n) * P.ld_out + 4 * g;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (4 * g + i < C) o[i] = cep[i];
-                }
+                if (t0 + n < T) store_quad(t0 + n, g, 0, cep);
             } else {
                 // ------------------------------------------------------------ 6b. delta, delta-delta, rows
-                // cb: cepstra of frames t0 - 8 .. t0 + 15 in rows 0 .. 23 (rows 0..7: the previous tile's last eight);
-                // db: deltas, same rows, used by the first / last tile of an utterance only
-                float* const cb = cring;
-                float* const db = dring;
+                // cb: cepstra of frames t0 - 8 .. t0 + 15 in rows 0 .. 23 (rows 0..7: the previous tile's last eight)
                 const int fo = lane & 15, cq = lane >> 4;
                 const float inv = P.inv_den;
                 *reinterpret_cast<m512_f4*>(cb + (8 + n) * 16 + 4 * g) = cep;
                 M512_LDS_FENCE();
-                const bool first = j == 0, last = j == J - 1;
-                auto copy_out = [&](int f_first, int nr) {   // rows f_first .. f_first + nr - 1 are contiguous in memory
-                    M512_LDS_FENCE();
-                    const int ne = nr * 3 * C;
-                    // bounds-checked stores: elements past the block's end are dropped by the descriptor, no exec masks
-                    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(
-                        out + (row0 + f_first) * (int64_t)(3 * C), 0, ne * 4, 0x00020000);
-                    float v[12];
-#pragma unroll
-                    for (int m = 0; m < 12; ++m) v[m] = obuf[ooff[m]];
-#pragma unroll
-                    for (int m = 0; m < 12; ++m)
-                        if (64 * m < ne) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v[m]), rs_o, (lane + 64 * m) * 4, 0, 0);
-                };
+                const bool first = t0 == 0, last = t0 + 16 >= T;
                 if (!first && !last) {
                     // interior tile: frame t0 - 4 + fo (row 4 + fo) with its whole window inside the utterance; delta of
                     // delta written out as ONE nine-tap filter (coefficients = the delta taps convolved with themselves)
@@ -564,24 +642,22 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
                             dd[i] = ((c9[6][i] + c9[2][i]) - 2.f * c9[4][i]) * (inv * inv);
                         }
                     }
-                    float* orow = obuf + fo * M512_OBUF_ROW + 4 * cq;
-                    *reinterpret_cast<m512_f4*>(orow) = c9[4];
-                    *reinterpret_cast<m512_f4*>(orow + 16) = d;
-                    *reinterpret_cast<m512_f4*>(orow + 32) = dd;
-                    copy_out(t0 - 4, 16);
+                    const int f = t0 - 4 + fo;
+                    store_quad(f, cq, 0, c9[4]);
+                    store_quad(f, cq, 1, d);
+                    store_quad(f, cq, 2, dd);
                 } else {
                     // first and / or last tile of the utterance: the windows are clamped to [0, T - 1] (edge padding of
-                    // base.py:73, once for delta and once more for delta of delta)
-                    const int Ti = (int)T;
-                    const int dlo = first ? 0 : t0 - 6, dhi = last ? Ti : t0 + 14;
-                    const int olo = first ? 0 : t0 - 4, ohi = last ? Ti : t0 + 12;
+                    // base.py:73, once for delta and once more for delta of delta); deltas go through db
+                    const int dlo = first ? 0 : t0 - 6, dhi = last ? T : t0 + 14;
+                    const int olo = first ? 0 : t0 - 4, ohi = last ? T : t0 + 12;
                     for (int f0 = dlo; f0 < dhi; f0 += 16) {
                         const int f = f0 + fo;
                         if (f < dhi) {
                             m512_f4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                             for (int k = 1; k <= ND; ++k) {
-                                const int ra = 8 + min(f + k, Ti - 1) - t0, rb = 8 + max(f - k, 0) - t0;
+                                const int ra = 8 + min(f + k, T - 1) - t0, rb = 8 + max(f - k, 0) - t0;
                                 const m512_f4 a = *reinterpret_cast<const m512_f4*>(cb + ra * 16 + 4 * cq);
                                 const m512_f4 bq = *reinterpret_cast<const m512_f4*>(cb + rb * 16 + 4 * cq);
 #pragma unroll
@@ -599,7 +675,7 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
                             m512_f4 dd = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                             for (int k = 1; k <= ND; ++k) {
-                                const int ra = 8 + min(f + k, Ti - 1) - t0, rb = 8 + max(f - k, 0) - t0;
+                                const int ra = 8 + min(f + k, T - 1) - t0, rb = 8 + max(f - k, 0) - t0;
                                 const m512_f4 a = *reinterpret_cast<const m512_f4*>(db + ra * 16 + 4 * cq);
                                 const m512_f4 bq = *reinterpret_cast<const m512_f4*>(db + rb * 16 + 4 * cq);
 #pragma unroll
@@ -607,12 +683,10 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
                             }
 #pragma unroll
                             for (int i = 0; i < 4; ++i) dd[i] *= inv;
-                            float* orow = obuf + fo * M512_OBUF_ROW + 4 * cq;
-                            *reinterpret_cast<m512_f4*>(orow) = *reinterpret_cast<const m512_f4*>(cb + (8 + f - t0) * 16 + 4 * cq);
-                            *reinterpret_cast<m512_f4*>(orow + 16) = *reinterpret_cast<const m512_f4*>(db + (8 + f - t0) * 16 + 4 * cq);
-                            *reinterpret_cast<m512_f4*>(orow + 32) = dd;
+                            store_quad(f, cq, 0, *reinterpret_cast<const m512_f4*>(cb + (8 + f - t0) * 16 + 4 * cq));
+                            store_quad(f, cq, 1, *reinterpret_cast<const m512_f4*>(db + (8 + f - t0) * 16 + 4 * cq));
+                            store_quad(f, cq, 2, dd);
                         }
-                        copy_out(f0, min(16, ohi - f0));
                     }
                 }
                 M512_LDS_FENCE();
@@ -620,13 +694,7 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
                     const int r = lane >> 2, qd = lane & 3;
                     *reinterpret_cast<m512_f4*>(cb + r * 16 + 4 * qd) = *reinterpret_cast<const m512_f4*>(cb + (16 + r) * 16 + 4 * qd);
                 }
-                // obuf lies over the first planes of the hi image: the rows of those planes that no staging pass
-                // rewrites (4 RQ .. PS - 1, read against zero window rows by the tile's last frames) must be finite again
                 M512_LDS_FENCE();
-                if constexpr (PS > 4 * RQ) {
-                    static_assert((PS - 4 * RQ) == 8, "pad rows are one 16-byte store per plane");
-                    if (lane < 16) *reinterpret_cast<m512_u4*>(imgHi + lane * PS * 2 + 4 * RQ * 2) = m512_u4{0u, 0u, 0u, 0u};
-                }
             }
             M512_STAMP(6);
 #ifdef M512_STAMPS
@@ -651,11 +719,15 @@ __global__ __launch_bounds__(64 * M512_WAVES, 1) void mfcc512m_kernel(M512Params
 // --------------------------------------------------------------------------------------------- host side
 #ifndef M512_KERNEL_ONLY
 
-static inline bool mfma512_disabled() {
+// The matrix-pipe kernel is an opt-in path (measured slower than the vector-pipe kernel at this stage):
+// DSP_MFMA512=1 in the environment, or dsp_debug_use_mfma512(1) for the calling thread.
+thread_local int g_use_mfma512 = -1;   // -1: follow the environment
+static inline bool mfma512_enabled() {
+    if (g_use_mfma512 >= 0) return g_use_mfma512 == 1;
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("DSP_MFMA512");
-        v = (e && e[0] == '0') ? 1 : 0;
+        v = (e && e[0] == '1') ? 1 : 0;
     }
     return v == 1;
 }
@@ -671,8 +743,6 @@ static inline int mfma512_plan_init(dsp_plan* p, const dsp_plan_desc* d) {
     if (rc != 0) return DSP_OK;                               // not served: the other kernels take the plan
     Mfma512Plan* mp = new Mfma512Plan();
     mp->lay = lay;
-    const int rows = 15 * (d->frame_step / 16) + lay.KR;
-    mp->rq = rows <= 176 ? 44 : 48;
     if (hipMalloc(&mp->d_tables, blob.size()) != hipSuccess) { delete mp; return DSP_EHIP; }
     if (hipMemcpy(mp->d_tables, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipFree(mp->d_tables);
@@ -702,25 +772,25 @@ static inline int mfma512_device_cus() {
     return cus;
 }
 
-// dense batches only: every utterance `uniform_samples` long, at least one utterance per wave slot of the chip
+// dense batches only: every utterance `uniform_samples` long, enough frames to give every wave slot of the chip a tile
 static inline bool mfma512_applicable(const dsp_plan* p, const BatchGeom& bg, int dtype, int delta_n) {
-    if (!p->d_mfma || mfma512_disabled()) return false;
+    if (!p->d_mfma || !mfma512_enabled()) return false;
     if (bg.uniform_samples <= 0 || bg.seg) return false;
     if (dtype != DSP_WAVE_F32 && dtype != DSP_WAVE_I16) return false;
     if (delta_n < 0 || delta_n > 2) return false;
-    if (bg.uniform_samples * 4 >= ((int64_t)1 << 31)) return false;
-    if (bg.n_utt < mfma512_device_cus() * M512_WAVES / 2) return false;
+    if (bg.uniform_samples * 4 >= ((int64_t)1 << 31) || bg.uniform_frames >= ((int64_t)1 << 24)) return false;
+    if (bg.total_frames < (int64_t)mfma512_device_cus() * M512_WAVES * 16) return false;
     return true;
 }
 
-template <int RQ, int DTYPE, int NMT, int ND>
+template <int DTYPE, int NMT, int ND, int WAVES>
 static int mfma512_launch_k(const M512Params& P, const void* d_wave, float* d_out, hipStream_t st) {
     constexpr int HS = 10;
-    constexpr int PS = ((15 * HS + 32 > 4 * RQ ? 15 * HS + 32 : 4 * RQ) + 3) / 4 * 4;
-    constexpr int WAVE_BYTES = 2 * 16 * PS * 2 + 2 * M512_RING * 16 * 4;
-    const size_t lds = 65536 + (size_t)16 * 2048 + (size_t)M512_WAVES * WAVE_BYTES;
-    if (lds > 163840) return 1;
-    auto kern = mfcc512m_kernel<HS, RQ, DTYPE, NMT, ND>;
+    constexpr int WAVE_BYTES = 2 * 8 * 192 * 2 + 24 * 64;
+    constexpr int NWB = m512_octet_blocks<NMT>(0) + m512_octet_blocks<NMT>(1);
+    const size_t lds = 65536 + (size_t)NWB * 2048 + (size_t)WAVES * WAVE_BYTES;
+    static_assert(65536 + NWB * 2048 + WAVES * WAVE_BYTES <= 163840, "LDS budget");
+    auto kern = mfcc512m_kernel<HS, DTYPE, NMT, ND, WAVES>;
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess)
@@ -728,9 +798,10 @@ static int mfma512_launch_k(const M512Params& P, const void* d_wave, float* d_ou
         attr_set = true;
     }
     int grid = mfma512_device_cus();
-    const int need = (P.n_utt + M512_WAVES - 1) / M512_WAVES;
+    const int64_t items = (int64_t)P.n_utt * P.splits;
+    const int need = (int)((items + WAVES - 1) / WAVES);
     if (grid > need) grid = need;
-    kern<<<grid, 64 * M512_WAVES, lds, st>>>(P, d_wave, d_out);
+    kern<<<grid, 64 * WAVES, lds, st>>>(P, d_wave, d_out);
     return hipGetLastError() == hipSuccess ? DSP_OK : DSP_EHIP;
 }
 
@@ -754,18 +825,29 @@ static inline int mfma512_launch(const dsp_plan* p, const void* d_wave, int dtyp
     P.frames = bg.uniform_frames;
     {
         static int stg = -1;
-        if (stg < 0) { const char* e = getenv("DSP_M512_STAGGER"); stg = e ? atoi(e) : 4; }
+        if (stg < 0) { const char* e = getenv("DSP_M512_STAGGER"); stg = e ? atoi(e) : 2; }
         P.stagger = stg;
     }
+    static int waves = 0;
+    if (waves == 0) { const char* e = getenv("DSP_M512_WAVES"); waves = (e && atoi(e) == 4) ? 4 : 8; }
+    // fewer utterances than wave slots: every utterance is cut into row ranges (each range recomputes 8 + 4 frames
+    // of its neighbours for the delta windows), as many as keep a range at two tiles or more
+    {
+        const int64_t slots = (int64_t)mfma512_device_cus() * waves;
+        int splits = 1;
+        while ((int64_t)bg.n_utt * splits < slots && bg.uniform_frames / (splits + 1) >= 32 && splits < 64) ++splits;
+        if (const char* e = getenv("DSP_M512_SPLITS")) splits = atoi(e) > 0 ? atoi(e) : splits;
+        P.splits = splits;
+    }
     const int nmt = mp->lay.n_mtiles;
-#define M512_LAUNCH(RQ_, DT_, NMT_, ND_) return mfma512_launch_k<RQ_, DT_, NMT_, ND_>(P, d_wave, d_out, st)
-#define M512_LAUNCH_NMT(RQ_, DT_, ND_) \
-    do { if (nmt <= 2) M512_LAUNCH(RQ_, DT_, 2, ND_); else M512_LAUNCH(RQ_, DT_, 3, ND_); } while (0)
-#define M512_LAUNCH_DT(RQ_, ND_) \
-    do { if (dtype == DSP_WAVE_I16) M512_LAUNCH_NMT(RQ_, DSP_WAVE_I16, ND_); else M512_LAUNCH_NMT(RQ_, DSP_WAVE_F32, ND_); } while (0)
-#define M512_LAUNCH_ND(RQ_) \
-    do { if (delta_n == 0) M512_LAUNCH_DT(RQ_, 0); else if (delta_n == 1) M512_LAUNCH_DT(RQ_, 1); else M512_LAUNCH_DT(RQ_, 2); } while (0)
-    if (mp->rq == 44) M512_LAUNCH_ND(44); else M512_LAUNCH_ND(48);
+#define M512_LAUNCH(DT_, NMT_, ND_) \
+    do { if (waves == 4) return mfma512_launch_k<DT_, NMT_, ND_, 4>(P, d_wave, d_out, st); \
+         return mfma512_launch_k<DT_, NMT_, ND_, 8>(P, d_wave, d_out, st); } while (0)
+#define M512_LAUNCH_NMT(DT_, ND_) \
+    do { if (nmt <= 2) M512_LAUNCH(DT_, 2, ND_); else M512_LAUNCH(DT_, 3, ND_); } while (0)
+#define M512_LAUNCH_DT(ND_) \
+    do { if (dtype == DSP_WAVE_I16) M512_LAUNCH_NMT(DSP_WAVE_I16, ND_); else M512_LAUNCH_NMT(DSP_WAVE_F32, ND_); } while (0)
+    if (delta_n == 0) M512_LAUNCH_DT(0); else if (delta_n == 1) M512_LAUNCH_DT(1); else M512_LAUNCH_DT(2);
     return 1;
 }
 #endif  // M512_KERNEL_ONLY

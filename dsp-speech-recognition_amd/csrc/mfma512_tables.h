@@ -48,7 +48,7 @@ struct M512Layout {
 
 // The mel blocks the kernel multiplies (compile-time there: kernels_mfma512.h m512_has_block).
 static inline bool m512_pattern_has(int n_mtiles, int step, int tile) {
-    return n_mtiles <= 2 ? true : (tile == 1 || (tile == 0 && step < 4) || (tile == 2 && step >= 4));
+    return n_mtiles <= 2 ? true : (tile == 1 || (tile == 0 && step < 2) || (tile == 2 && step >= 4));
 }
 
 static inline uint16_t m512_f2h(float f) {  // round-to-nearest-even, subnormals kept

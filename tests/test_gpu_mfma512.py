@@ -1,0 +1,131 @@
+"""GPU parity of the matrix-pipe NFFT = 512 kernel (csrc/kernels_mfma512.h, opt-in through dsp_debug_use_mfma512).
+The path replaces sigproc.preemphasis / framesig / powspec and base.fbank / mfcc / delta (sigproc.py:66-98,136-158,
+178-185; base.py:8-32,70-79) for dense batches; the oracle is the checker, the vector-pipe kernel a second opinion."""
+import numpy as np
+import pytest
+
+from conftest import normwise, record
+from oracle import dsp_oracle
+import golden_cases as gc
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(samplerate=16000, winlen=0.025, winstep=0.01, numcep=13, nfilt=40, nfft=512, lowfreq=0,
+           highfreq=None, preemph=0.97, ceplifter=22, appendEnergy=True)
+TOL = 1e-4
+KINDS = ('white', 'tone', 'harmonic', 'siltail', 'vadf', 'ramp', 'zeros', 'uniform')
+
+
+class _Mfma:
+    """Routes the calling thread's dense MFCC calls to the matrix-pipe kernel for the duration of a with-block."""
+
+    def __enter__(self):
+        from features import _native as nat
+        nat.check(nat.load().dsp_debug_use_mfma512(1))
+
+    def __exit__(self, *a):
+        from features import _native as nat
+        nat.check(nat.load().dsp_debug_use_mfma512(-1))
+
+
+def _batch(B, N, seed=3, dtype=np.float32):
+    """The first utterances are the golden signal kinds (tone-like, silent tails, a ramp whose pre-emphasised samples
+    are 30x smaller than the raw ones, digital zero); the rest white noise over four decades of amplitude."""
+    rng = np.random.default_rng(seed)
+    x = np.empty((B, N), np.float64)
+    for b in range(B):
+        if b < 2 * len(KINDS):
+            x[b] = np.asarray(gc.make_signal((KINDS[b % len(KINDS)], 100 + b, N)), np.float64)[:N]
+        else:
+            x[b] = 0.25 * rng.standard_normal(N) * (10.0 ** rng.uniform(-3, 1))
+    if dtype == np.int16:
+        return np.clip(np.round(x * 3000), -32768, 32767).astype(np.int16)
+    return x.astype(np.float32)
+
+
+def _plan(**over):
+    from features.batch import FeaturePlan
+    return FeaturePlan(winfunc=np.hamming, **dict(CFG, **over))
+
+
+def _served(plan):
+    from features import _native as nat
+    return nat.load().dsp_plan_has_mfma512(plan.plan.handle) == 1
+
+
+def _worst(got, fo, waves, cfg, delta_n, idx):
+    worst = 0.0
+    for b in idx:
+        x = waves[b].astype(np.float64)
+        ref = dsp_oracle.mfcc_delta(x, delta_n=delta_n, winfunc=np.hamming, **cfg) if delta_n else \
+            dsp_oracle.mfcc(x, winfunc=np.hamming, **cfg)
+        g = got[fo[b]:fo[b + 1]]
+        assert g.shape == ref.shape and np.isfinite(g).all(), b
+        worst = max(worst, normwise(g, ref))
+    return worst
+
+
+@pytest.mark.parametrize('name,over,B,N,delta_n,dtype', [
+    ('configs1_rows', {}, 1024, 16000, 2, np.float32),
+    ('configs1_cepstra', {}, 1024, 16000, 0, np.float32),
+    ('configs1_int16', {}, 1024, 16000, 2, np.int16),
+    ('nfilt26', dict(nfilt=26), 1024, 16000, 2, np.float32),
+    ('odd_length', {}, 777, 12345, 2, np.float32),          # N not a multiple of anything: partial last loads
+    ('delta1_long', {}, 300, 48000, 1, np.float32),
+    ('winlen20ms', dict(winlen=0.02), 640, 16000, 2, np.float32),
+    ('no_energy_no_lifter', dict(appendEnergy=False, ceplifter=0), 600, 16000, 2, np.float32),
+])
+def test_matrix_pipe_kernel_vs_oracle(name, over, B, N, delta_n, dtype):
+    cfg = dict(CFG, **over)
+    plan = _plan(**over)
+    assert _served(plan)
+    waves = _batch(B, N, dtype=dtype)
+    with _Mfma():
+        got, fo = plan.mfcc_batch(waves, delta_n=delta_n)
+    idx = list(range(0, 2 * len(KINDS))) + list(range(2 * len(KINDS), B, max(1, B // 24))) + [B - 1]
+    worst = record('mfma512_' + name, _worst(got, fo, waves, cfg, delta_n, idx))
+    assert worst <= TOL, worst
+
+
+def test_matrix_pipe_and_vector_pipe_kernels_agree():
+    """Two independent implementations of the same path (fp16-split matrix products vs in-register fp32 butterflies)."""
+    plan = _plan()
+    waves = _batch(1024, 16000, seed=9)
+    vec, fo = plan.mfcc_batch(waves, delta_n=2)
+    with _Mfma():
+        mat, fo2 = plan.mfcc_batch(waves, delta_n=2)
+    assert np.array_equal(fo, fo2)
+    worst = max(normwise(mat[fo[b]:fo[b + 1]], vec[fo[b]:fo[b + 1]]) for b in range(0, 1024, 7))
+    assert record('mfma512_vs_vector_pipe', worst) <= TOL
+
+
+def test_matrix_pipe_results_do_not_depend_on_the_batch():
+    """A wave owns whole row ranges of ONE utterance and scales each 16-frame tile by its own largest sample, so an
+    utterance's rows are the same bits whatever surrounds it -- as long as it is cut into the same ranges: the same
+    utterance in two batches of one size, at different positions, next to different neighbours."""
+    plan = _plan()
+    a = _batch(1024, 16000, seed=21)
+    b = a[::-1].copy()
+    b[500] = np.nan                                    # a NaN clip must not leak into its neighbours
+    with _Mfma():
+        ra, fo = plan.mfcc_batch(a, delta_n=2)
+        rb, _ = plan.mfcc_batch(b, delta_n=2)
+    ra = ra.reshape(1024, 99, 39)
+    rb = rb.reshape(1024, 99, 39)[::-1]
+    keep = np.ones(1024, bool)
+    keep[1023 - 500] = False
+    assert np.array_equal(ra[keep], rb[keep])
+    assert np.isnan(rb[1023 - 500]).any()
+
+
+def test_plans_outside_the_kernel_fall_back():
+    """More than 47 filters, a hop that is not 160 samples, a filterbank outside the block pattern: the plan carries no
+    matrix-pipe tables and the switch changes nothing."""
+    waves = _batch(600, 16000, seed=5)
+    for over in (dict(nfilt=64), dict(winstep=0.0125), dict(lowfreq=3000)):
+        plan = _plan(**over)
+        assert not _served(plan), over
+        ref, fo = plan.mfcc_batch(waves, delta_n=2)
+        with _Mfma():
+            got, _ = plan.mfcc_batch(waves, delta_n=2)
+        assert np.array_equal(got, ref), over

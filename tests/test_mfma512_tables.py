@@ -1,0 +1,60 @@
+"""CPU checks of the matrix-pipe kernel's host side: the operand tables of csrc/mfma512_tables.h, pushed through an
+emulation of the kernel's data path (tools/mfma512_emul.py: fp16 / bf16 roundings and the MFMA operand maps in NumPy),
+must reproduce the oracle's MFCCs (base.py:8-16) -- a wrong table, K order or scale shows up here without a GPU."""
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, normwise
+from oracle import dsp_oracle
+import golden_cases as gc
+
+SO = '/tmp/m512_tab.so'
+
+
+@pytest.fixture(scope='module')
+def emul():
+    if shutil.which('g++') is None:
+        pytest.skip('no g++')
+    subprocess.run(['g++', '-O2', '-shared', '-fPIC', '-o', SO, os.path.join(ROOT, 'tools', 'mfma512_tables_c.cpp')], check=True)
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import mfma512_emul
+    return mfma512_emul
+
+
+@pytest.mark.parametrize('nfilt,L,win', [(40, 400, np.hamming), (26, 400, np.hamming), (40, 320, np.hamming),
+                                          (40, 512, dsp_oracle._ones)])
+def test_tables_reproduce_the_oracle(emul, nfilt, L, win):
+    blob, lay = emul.build(L=L, S=160, nfilt=nfilt, win=win)
+    assert lay['n_mtiles'] == (nfilt + 1 + 15) // 16 and len(lay['wblocks']) == (16 if nfilt <= 31 else 14)
+    for kind in ('white', 'tone', 'ramp', 'siltail'):
+        sig = gc.make_signal((kind, 30, 4000))
+        cfg = dict(gc.BASE_CFG, nfilt=nfilt, winlen=L / 16000.0, winfunc=win)
+        ref = dsp_oracle.mfcc(sig, **cfg)
+        got = emul.mfcc_emul(sig, blob, lay, L=L, S=160)[:, :13]
+        assert normwise(got, ref) <= 1e-4, (kind, normwise(got, ref))
+
+
+def test_plans_the_kernel_does_not_serve_are_refused(emul):
+    import ctypes as C
+    from features import _plan as P
+    lib = C.CDLL(SO)
+
+    def rc(L=400, S=160, nfilt=40, lowfreq=0, numcep=13):
+        window = np.ascontiguousarray(np.hamming(L), np.float32)
+        fb = P.filterbank_matrix(nfilt, 512, 16000, lowfreq, None)
+        st, cnt, w = P.mel_csr(fb)
+        dct = np.ascontiguousarray(P.dct_lifter_matrix(nfilt, numcep, 22), np.float32)
+        out = np.zeros(1 << 20, np.uint8)
+        lay = np.zeros(64, np.int32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        return lib.m512_tables(L, S, 512, nfilt, numcep, 1, p(window), p(st), p(cnt), p(w), p(dct), p(out), out.size, p(lay))
+
+    assert rc() == 0
+    assert rc(nfilt=64) == -1          # more rows than three tiles of 16
+    assert rc(S=200) == -1             # hop not a multiple of 16 samples
+    assert rc(lowfreq=3000) == -3      # filters of the lowest tile reach beyond the lowest quarter of the spectrum
