@@ -272,6 +272,31 @@ def other_paths(dev):
     plan = FeaturePlan(winfunc=np.hamming, **CFG)
     share_out, out['configs2_share'] = share_launch(dev, plan)
     del share_out
+    # --- the opt-in matrix-pipe kernel (csrc/kernels_mfma512.h) on the metric's workload, for the record: one launch
+    #     = the whole step; same algorithmic bytes as the step's fused kernel ---
+    if lib.dsp_plan_has_mfma512(plan.plan.handle) == 1:
+        lay1 = plan.layout(np.empty((B, N), dtype=np.float32))
+        g = torch.Generator(device=dev).manual_seed(3)
+        w1 = [0.25 * torch.randn((B, N), device=dev, generator=g) for _ in range(4)]
+        o1 = torch.empty((lay1.total_frames, 3 * CFG['numcep']), device=dev)
+        k = [0]
+
+        def one():
+            k[0] += 1
+            plan.run_raw(w1[k[0] % 4].data_ptr(), nat.WAVE_F32, lay1, o1.data_ptr(), DELTA_N, st)
+        nat.check(lib.dsp_debug_use_mfma512(1))
+        try:
+            us = timed(one, reps=100)
+        finally:
+            nat.check(lib.dsp_debug_use_mfma512(-1))
+        byt = 4.0 * B * N + 4.0 * lay1.total_frames * 3 * CFG['numcep']
+        out['mfma512_kernel'] = {
+            'kernel': 'mfcc512m_kernel: DFT, mel and DCT as fp16 / bf16 (hi, lo) products on v_mfma_f32_16x16x32, opt-in '
+                      '(dsp_debug_use_mfma512); NOT the path `value` times',
+            'workload': f'{B} x 1 s, MFCC+delta+delta2 rows in one launch', 'us_per_launch': us,
+            'frames_per_s': lay1.total_frames / us * 1e6, 'algorithmic_GBps': byt / us / 1e3,
+            'frac_of_hbm_roofline': byt / us / 1e3 / HBM_PEAK_GBPS}
+        del w1, o1
     return out
 
 

@@ -42,7 +42,7 @@ def main():
         run()
     raw.dsp_debug_read_stamps_m512(buf, 16)
     tiles = buf[7]
-    names = ['loop / first fetch', 'staging', 'stage 1', 'fetch issue', 'transpose', 'stage 2 + power + mel', 'log + DCT', 'delta + rows out']
+    names = ['loop + wait for samples', 'tile scale + staging half 0', 'stage 1 (+ staging half 1)', '(unused)', 'transpose + stage 2 + mel', 'log2 + DCT', 'delta + row stores']
     tot = sum(buf[i] for i in range(7))
     for i in range(7):
         print(f'  {names[i] if i < 1 else names[i]:26s} {buf[i] / tiles:8.0f} cycles/tile  {100.0 * buf[i] / tot:5.1f} %')
