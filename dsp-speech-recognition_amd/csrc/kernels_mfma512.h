@@ -38,6 +38,10 @@ typedef float m512_f2 __attribute__((ext_vector_type(2)));
 typedef __bf16 m512_b2 __attribute__((ext_vector_type(2)));
 
 #define M512_WAVES 8
+#ifndef M512_AHEAD
+#define M512_AHEAD 1          // stage 1: operand columns in flight (2: +1.5 %, 6 spilled registers)
+#endif
+#define M512_NBUF (M512_AHEAD + 1)
 #ifndef M512_FETCH_SLOT
 #define M512_FETCH_SLOT 11   // stage-2 slot after which the next tile's samples are requested
 #endif
@@ -352,8 +356,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void mfcc512m_kernel(M512Par
             // ---------------------------------------------------------------- 2. staging + stage 1, half by half
             uint32_t Rh[4][4][4], Rl[4][4][4];                        // [n2 >> 2][n2 & 3][i]: (re, im) of row 4 g + i
             m512_f4 accp[2];
-            uint32_t bh[2][4], bl[2][4];
-            m512_h8 ah[2][2], al[2][2];
+            uint32_t bh[M512_NBUF][4], bl[M512_NBUF][4];
+            m512_h8 ah[M512_NBUF][2], al[M512_NBUF][2];
             auto stage_half = [&](auto hc_) {
                 constexpr int h = decltype(hc_)::value;
                 // rows 2 l and 2 l + 1: the two rows of a plane share a dword
@@ -391,10 +395,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void mfcc512m_kernel(M512Par
                     *reinterpret_cast<uint16_t*>(imgLo + 2 * ((e + 1) * PS + 128) + 2 * lane) = (uint16_t)(ll >> 16);
                 }
             };
-            // the operands of column n2 + 1 are read while the products of column n2 run
+            // the operands of column n2 + M512_AHEAD are requested while the products of column n2 run (the compiler pulls
+            // a column's products up to one column forward, so one column ahead in the source is less than an LDS
+            // latency in the instruction stream)
             auto load_ops = [&](auto nc_) {
                 constexpr int n2 = decltype(nc_)::value;
-                constexpr int sl = n2 & 1, pl = n2 & 7;
+                constexpr int sl = n2 % M512_NBUF, pl = n2 & 7;
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     bh[sl][d] = bHi[(2 * pl * PS + 4 * d) / 4];
@@ -408,8 +414,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void mfcc512m_kernel(M512Par
             };
             auto column = [&](auto nc_) {
                 constexpr int n2 = decltype(nc_)::value;
-                constexpr int sl = n2 & 1;
-                if constexpr ((n2 & 7) != 7) load_ops(std::integral_constant<int, ((n2 & 7) != 7 ? n2 + 1 : 0)>{});
+                constexpr int sl = n2 % M512_NBUF;
+                if constexpr ((n2 & 7) + M512_AHEAD <= 7) load_ops(std::integral_constant<int, ((n2 & 7) + M512_AHEAD <= 7 ? n2 + M512_AHEAD : 0)>{});
                 const m512_h8 Bh = m512_as_h8(bh[sl][0], bh[sl][1], bh[sl][2], bh[sl][3]);
                 const m512_h8 Bl = m512_as_h8(bl[sl][0], bl[sl][1], bl[sl][2], bl[sl][3]);
                 const m512_f4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -427,11 +433,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void mfcc512m_kernel(M512Par
             M512_LDS_FENCE();
             M512_STAMP(1);
             load_ops(std::integral_constant<int, 0>{});
+            if constexpr (M512_AHEAD > 1) load_ops(std::integral_constant<int, 1>{});
             m512_static_for<0, 8>(column);
             M512_LDS_FENCE();
             stage_half(std::integral_constant<int, 1>{});
             M512_LDS_FENCE();
             load_ops(std::integral_constant<int, 8>{});
+            if constexpr (M512_AHEAD > 1) load_ops(std::integral_constant<int, 9>{});
             m512_static_for<8, 16>(column);
 #pragma unroll
             for (int i = 0; i < 4; ++i) m512_split_f16(accp[0][i], accp[1][i], Rh[3][3][i], Rl[3][3][i]);
