@@ -38,6 +38,9 @@ typedef float m512_f2 __attribute__((ext_vector_type(2)));
 typedef __bf16 m512_b2 __attribute__((ext_vector_type(2)));
 
 #define M512_WAVES 8
+#ifndef M512_PREFETCH
+#define M512_PREFETCH 0       // 1: request the next tile's samples after stage 2 (spills 71 registers: measured slower)
+#endif
 #ifndef M512_AHEAD
 #define M512_AHEAD 1          // stage 1: operand columns in flight (2: +1.5 %, 6 spilled registers)
 #endif
@@ -209,12 +212,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void mfcc512m_kernel(M512Par
     constexpr int ESZ = DTYPE == DSP_WAVE_I16 ? 2 : 4;
     constexpr bool ROWS = ND > 0;                 // ND: delta window (base.py:70-79), 0 = cepstra only
     constexpr int NWB = m512_octet_blocks<NMT>(0) + m512_octet_blocks<NMT>(1);
+    // the single-use matrices (stage 2 of slot 0, DCT) live in what LDS is left: 4 KB always, 4 more when they fit
+    constexpr bool DM_LDS = 65536 + NWB * 2048 + 8192 + WAVES * WAVE_BYTES <= 163840;
+    constexpr int XTRA = DM_LDS ? 8192 : 4096;
     extern __shared__ __attribute__((aligned(16))) uint8_t m512_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint8_t* const sA1 = m512_smem;
     uint8_t* const sW = m512_smem + 65536;
-    uint8_t* const sWave = m512_smem + 65536 + NWB * 2048 + wv * WAVE_BYTES;
+    uint8_t* const sA2p = m512_smem + 65536 + NWB * 2048;
+    uint8_t* const sDm = sA2p + 4096;
+    uint8_t* const sWave = m512_smem + 65536 + NWB * 2048 + XTRA + wv * WAVE_BYTES;
     uint8_t* const imgHi = sWave;
     uint8_t* const imgLo = sWave + IMG_BYTES;
     float* const cb = reinterpret_cast<float*>(sWave + 2 * IMG_BYTES);   // cepstra of frames t0 - 8 .. t0 + 15
@@ -271,6 +279,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void mfcc512m_kernel(M512Par
         const m512_u4* srcw = reinterpret_cast<const m512_u4*>(P.tables + P.lay.off_w);
         m512_u4* dstw = reinterpret_cast<m512_u4*>(sW);
         for (int i = tid; i < NWB * 128; i += 64 * WAVES) dstw[i] = srcw[i];
+        const m512_u4* srca = reinterpret_cast<const m512_u4*>(P.tables + P.lay.off_a2p);   // a2p, then dm: adjacent in the blob
+        m512_u4* dsta = reinterpret_cast<m512_u4*>(sA2p);
+        for (int i = tid; i < XTRA / 16; i += 64 * WAVES) dsta[i] = srca[i];
         m512_u4* z = reinterpret_cast<m512_u4*>(sWave);
         const m512_u4 zero = {0, 0, 0, 0};
         for (int i = lane; i < WAVE_BYTES / 16; i += 64) z[i] = zero;
@@ -320,7 +331,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void mfcc512m_kernel(M512Par
             // stage 2, so every tile requests its samples here and the other wave of the SIMD computes meanwhile (any
             // later request point spills, and a spill reload waits for the outstanding sample loads).  One wave per
             // SIMD (512 registers): the next tile's samples are requested right after stage 1, below.
-            if (WAVES == 8 || j == 0) fetch(t0);
+            if ((WAVES == 8 && !M512_PREFETCH) || j == 0) fetch(t0);
             M512_STAMP(0);
             // ---------------------------------------------------------------- 1. scale of the tile
             float mx = fmaxf(fabsf(pa[0][0]), fabsf(pa[1][0]));
@@ -538,13 +549,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void mfcc512m_kernel(M512Par
                     m512_static_for<0, NB>(mul_w);
                 }
             };
-            // slot 0 (DFT rows 0 and 16) has its own matrix, read from memory (L2) for this one use
+            // slot 0 (DFT rows 0 and 16) has its own matrix, read from LDS for this one use
             m512_h8 a2p[2][2];
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int hl = 0; hl < 2; ++hl)
-                    a2p[u][hl] = reinterpret_cast<const m512_h8*>(P.tables + P.lay.off_a2p + (u * 2 + hl) * 1024)[lane];
+                    a2p[u][hl] = reinterpret_cast<const m512_h8*>(sA2p + (u * 2 + hl) * 1024)[lane];
             auto run_slot = [&](auto sc_) {
                 constexpr int s = decltype(sc_)::value;
                 constexpr int sig = s >> 2, i = s & 3;
@@ -573,13 +584,22 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void mfcc512m_kernel(M512Par
 #endif
             M512_STAMP(4);
 
+            // The stage-1 registers are dead: the next tile's samples travel through the log / DCT / delta phase.  The
+            // scheduling barriers keep hipcc from pulling the loads up into stage 2, where their 54 destination registers
+            // do not fit (it did: 77 spilled registers, and a spill reload then waits for the sample loads).
+            if constexpr (M512_PREFETCH) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + 1 < J) fetch(t0 + 16);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // ---------------------------------------------------------------- 5. log2, DCT * lifter, correction
             m512_h8 dmt[2][2];
 #pragma unroll
             for (int u = 0; u < (NMT > 2 ? 2 : 1); ++u)
 #pragma unroll
                 for (int hl = 0; hl < 2; ++hl)
-                    dmt[u][hl] = reinterpret_cast<const m512_h8*>(P.tables + P.lay.off_dm + (u * 2 + hl) * 1024)[lane];
+                    dmt[u][hl] = DM_LDS ? reinterpret_cast<const m512_h8*>(sDm + (u * 2 + hl) * 1024)[lane]
+                                        : reinterpret_cast<const m512_h8*>(P.tables + P.lay.off_dm + (u * 2 + hl) * 1024)[lane];
             const float zval = P.lay.z_log2_eps + corr;
             uint32_t leh[3][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}}, lel[3][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};
 #pragma unroll
@@ -796,8 +816,10 @@ static int mfma512_launch_k(const M512Params& P, const void* d_wave, float* d_ou
     constexpr int HS = 10;
     constexpr int WAVE_BYTES = 2 * 8 * 192 * 2 + 24 * 64;
     constexpr int NWB = m512_octet_blocks<NMT>(0) + m512_octet_blocks<NMT>(1);
-    const size_t lds = 65536 + (size_t)NWB * 2048 + (size_t)WAVES * WAVE_BYTES;
-    static_assert(65536 + NWB * 2048 + WAVES * WAVE_BYTES <= 163840, "LDS budget");
+    constexpr bool DM_LDS = 65536 + NWB * 2048 + 8192 + WAVES * WAVE_BYTES <= 163840;
+    constexpr int XTRA = DM_LDS ? 8192 : 4096;
+    const size_t lds = 65536 + (size_t)NWB * 2048 + XTRA + (size_t)WAVES * WAVE_BYTES;
+    static_assert(65536 + NWB * 2048 + XTRA + WAVES * WAVE_BYTES <= 163840, "LDS budget");
     auto kern = mfcc512m_kernel<HS, DTYPE, NMT, ND, WAVES>;
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
