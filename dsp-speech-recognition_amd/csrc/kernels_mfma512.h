@@ -236,7 +236,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void mfcc512m_kernel(M512Par
     // ---- this wave's work items: (utterance, part) -> rows [o_lo, o_hi) of the utterance
     const int nw_total = gridDim.x * WAVES, wglob = blockIdx.x * WAVES + wv;
     const int64_t n_items = (int64_t)P.n_utt * splits;
-    const int it_lo = (int)(n_items * wglob / nw_total), it_hi = (int)(n_items * (wglob + 1) / nw_total);
+    // exactly one item per wave and two items per utterance: pair the ranges inside the workgroup (see open_item)
+    const bool paired = WAVES == 8 && splits == 2 && n_items == (int64_t)nw_total;
+    const int it_base = blockIdx.x * WAVES;
+    const int it_lo = paired ? it_base + wv : (int)(n_items * wglob / nw_total);
+    const int it_hi = paired ? it_lo + 1 : (int)(n_items * (wglob + 1) / nw_total);
 
     // raw samples of one tile: half h (planes 8 h .. 8 h + 7): rows 2 l, 2 l + 1 (xa) and row 128 + l (xb) of the lane
     float xa[2][16], xb[2][8], pa[2][2], pb[2];
@@ -256,10 +260,24 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void mfcc512m_kernel(M512Par
         }
     };
     auto open_item = [&](int item, int& utt, int& o_lo, int& o_hi, int& c_lo, int& J) {
-        utt = item / splits;
-        const int part = item - utt * splits;
-        o_lo = (int)((int64_t)T * part / splits);
-        o_hi = (int)((int64_t)T * (part + 1) / splits);
+        int part;
+        if (paired) {   // two ranges per utterance, one range per wave: waves w and w + 4 (one SIMD) take a long and a short one
+            const int wl = item - it_base;            // == wave index in the workgroup
+            utt = (it_base >> 1) + (wl & 3);
+            part = wl >> 2;
+        } else {
+            utt = item / splits;
+            part = item - utt * splits;
+        }
+        // range boundaries at 16 k - 4: the range before ends with a full tile, and the tiles of both are as few as can be
+        auto bound = [&](int i) -> int {
+            if (i <= 0) return 0;
+            if (i >= splits) return T;
+            int b = ((int)(((int64_t)T * i / splits + 4 + 8) >> 4) << 4) - 4;
+            return b < 0 ? 0 : (b > T ? T : b);
+        };
+        o_lo = bound(part);
+        o_hi = bound(part + 1);
         c_lo = o_lo >= 8 ? o_lo - 8 : 0;                        // eight frames of history for the delta windows
         const int c_hi = o_hi + 4 < T ? o_hi + 4 : T;
         J = (c_hi - c_lo + 15) >> 4;
