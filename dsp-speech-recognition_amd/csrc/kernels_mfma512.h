@@ -65,6 +65,7 @@ struct M512Params {
     int64_t samples;       // per utterance
     int64_t frames;        // per utterance
     int32_t stagger;       // steps of 512 cycles between the start of consecutive waves of a workgroup
+    int32_t items_q, items_r;   // n_utt * splits = items_q * waves + items_r
     int32_t splits;        // work items per utterance (row ranges of equal size): > 1 when the batch has fewer utterances than waves
 };
 
@@ -239,8 +240,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void mfcc512m_kernel(M512Par
     // exactly one item per wave and two items per utterance: pair the ranges inside the workgroup (see open_item)
     const bool paired = WAVES == 8 && splits == 2 && n_items == (int64_t)nw_total;
     const int it_base = blockIdx.x * WAVES;
-    const int it_lo = paired ? it_base + wv : (int)(n_items * wglob / nw_total);
-    const int it_hi = paired ? it_lo + 1 : (int)(n_items * (wglob + 1) / nw_total);
+    // contiguous runs: P.items_q items per wave and P.items_r waves with one more, spread evenly over the grid
+    // (n_items = items_q * waves + items_r from the host; a remainder dealt to the FIRST waves would load whole CUs)
+    const uint32_t ex_lo = (uint32_t)wglob * (uint32_t)P.items_r / (uint32_t)nw_total;
+    const uint32_t ex_hi = (uint32_t)(wglob + 1) * (uint32_t)P.items_r / (uint32_t)nw_total;
+    const int it_lo = paired ? it_base + wv : wglob * P.items_q + (int)ex_lo;
+    const int it_hi = paired ? it_lo + 1 : (wglob + 1) * P.items_q + (int)ex_hi;
 
     // raw samples of one tile: half h (planes 8 h .. 8 h + 7): rows 2 l, 2 l + 1 (xa) and row 128 + l (xb) of the lane
     float xa[2][16], xb[2][8], pa[2][2], pb[2];
@@ -289,20 +294,27 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void mfcc512m_kernel(M512Par
     };
     int utt = 0, o_lo = 0, o_hi = 0, c_lo = 0, J = 0;
 
-    // ---- tables -> LDS (A1, mel blocks); image zeroed once (every row is rewritten by every staging pass)
+    // ---- tables -> LDS in one flat pass (A1 | mel blocks | slot-0 matrix, DCT): every load is in flight before the
+    //      first store; the wave's own region zeroed once (every image row is rewritten by every staging pass)
     {
-        const m512_u4* src = reinterpret_cast<const m512_u4*>(P.tables + P.lay.off_a1);
-        m512_u4* dst = reinterpret_cast<m512_u4*>(sA1);
-        for (int i = tid; i < 65536 / 16; i += 64 * WAVES) dst[i] = src[i];
-        const m512_u4* srcw = reinterpret_cast<const m512_u4*>(P.tables + P.lay.off_w);
-        m512_u4* dstw = reinterpret_cast<m512_u4*>(sW);
-        for (int i = tid; i < NWB * 128; i += 64 * WAVES) dstw[i] = srcw[i];
-        const m512_u4* srca = reinterpret_cast<const m512_u4*>(P.tables + P.lay.off_a2p);   // a2p, then dm: adjacent in the blob
-        m512_u4* dsta = reinterpret_cast<m512_u4*>(sA2p);
-        for (int i = tid; i < XTRA / 16; i += 64 * WAVES) dsta[i] = srca[i];
+        constexpr int TOTAL = 65536 + NWB * 2048 + XTRA, NK = (TOTAL / 16 + 64 * WAVES - 1) / (64 * WAVES);
+        m512_u4 tv[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int o = (tid + 64 * WAVES * k) * 16;
+            const uint8_t* src = o < 65536 ? P.tables + P.lay.off_a1 + o
+                                           : (o < 65536 + NWB * 2048 ? P.tables + P.lay.off_w + (o - 65536)
+                                                                     : P.tables + P.lay.off_a2p + (o - 65536 - NWB * 2048));
+            if (o < TOTAL) tv[k] = *reinterpret_cast<const m512_u4*>(src);
+        }
         m512_u4* z = reinterpret_cast<m512_u4*>(sWave);
         const m512_u4 zero = {0, 0, 0, 0};
         for (int i = lane; i < WAVE_BYTES / 16; i += 64) z[i] = zero;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int o = (tid + 64 * WAVES * k) * 16;
+            if (o < TOTAL) *reinterpret_cast<m512_u4*>(m512_smem + o) = tv[k];
+        }
     }
     // ---- register-resident: the stage-2 matrix of DFT rows 1..15 and the row sums of the DCT
     m512_h8 a2[2][2];
@@ -824,7 +836,7 @@ static inline bool mfma512_applicable(const dsp_plan* p, const BatchGeom& bg, in
     if (bg.uniform_samples <= 0 || bg.seg) return false;
     if (dtype != DSP_WAVE_F32 && dtype != DSP_WAVE_I16) return false;
     if (delta_n < 0 || delta_n > 2) return false;
-    if (bg.uniform_samples * 4 >= ((int64_t)1 << 31) || bg.uniform_frames >= ((int64_t)1 << 24)) return false;
+    if (bg.uniform_samples * 4 >= ((int64_t)1 << 31) || bg.uniform_frames >= ((int64_t)1 << 24) || (int64_t)bg.n_utt * 64 >= ((int64_t)1 << 31)) return false;
     if (bg.total_frames < (int64_t)mfma512_device_cus() * M512_WAVES * 16) return false;
     return true;
 }
@@ -849,7 +861,10 @@ static int mfma512_launch_k(const M512Params& P, const void* d_wave, float* d_ou
     const int64_t items = (int64_t)P.n_utt * P.splits;
     const int need = (int)((items + WAVES - 1) / WAVES);
     if (grid > need) grid = need;
-    kern<<<grid, 64 * WAVES, lds, st>>>(P, d_wave, d_out);
+    M512Params Q = P;
+    Q.items_q = (int32_t)(items / ((int64_t)grid * WAVES));
+    Q.items_r = (int32_t)(items % ((int64_t)grid * WAVES));
+    kern<<<grid, 64 * WAVES, lds, st>>>(Q, d_wave, d_out);
     return hipGetLastError() == hipSuccess ? DSP_OK : DSP_EHIP;
 }
 
