@@ -129,3 +129,36 @@ def test_plans_outside_the_kernel_fall_back():
         with _Mfma():
             got, _ = plan.mfcc_batch(waves, delta_n=2)
         assert np.array_equal(got, ref), over
+
+
+@pytest.mark.parametrize('N,B', [(300, 40000), (401, 36000), (1000, 8000), (2965, 2500)])
+def test_short_utterances(N, B):
+    """One frame with zero padding (N < L), two frames, a handful: the first tile is also the last, the delta windows
+    clamp on both sides, most of a tile's columns are padding."""
+    plan = _plan()
+    rng = np.random.default_rng(N)
+    waves = (0.25 * rng.standard_normal((B, N))).astype(np.float32)
+    with _Mfma():
+        got, fo = plan.mfcc_batch(waves, delta_n=2)
+    idx = list(range(0, B, max(1, B // 40))) + [B - 1]
+    assert record(f'mfma512_short_{N}', _worst(got, fo, waves, CFG, 2, idx)) <= TOL
+
+
+def test_extreme_amplitudes_and_silence():
+    """The tile scale is a power of two from the tile's largest sample: 1e-30 ... 1e30, exact zeros (the eps path of
+    base.py:26,30) and a clip that is silent except for one sample."""
+    plan = _plan()
+    B, N = 600, 16000
+    rng = np.random.default_rng(4)
+    waves = (0.25 * rng.standard_normal((B, N))).astype(np.float32)
+    amps = [1e-30, 1e-20, 1e-10, 1e10, 1e20, 1e30]
+    for i, a in enumerate(amps):
+        waves[i] *= np.float32(a)
+    waves[10] = 0.0
+    waves[11] = 0.0
+    waves[11, 7777] = 1.0
+    waves[12, 8000:] = 0.0
+    with _Mfma():
+        got, fo = plan.mfcc_batch(waves, delta_n=2)
+    assert np.isfinite(got).all()
+    assert record('mfma512_extremes', _worst(got, fo, waves, CFG, 2, list(range(16)) + [B - 1])) <= TOL
