@@ -714,6 +714,34 @@ __global__ __launch_bounds__(64) void endpoint_rule_kernel(const double* __restr
     }
 }
 
+// Inclusive prefix sums over the 64 lanes of a wave without LDS: row_shr 1, 2, 4, 8 inside each row of 16 lanes, then
+// row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3 (lanes without a source add zero).
+__device__ __forceinline__ int32_t dsp_wave_scan_i32(int32_t v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+__device__ __forceinline__ int64_t dsp_wave_scan_i64(int64_t v) {
+#define DSP_SCAN64_STEP(CTRL, ROWS)                                                                           \
+    {                                                                                                         \
+        const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(uint64_t)v, CTRL, ROWS, 0xf, false); \
+        const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)((uint64_t)v >> 32), CTRL, ROWS, 0xf, false); \
+        v += (int64_t)(((uint64_t)hi_ << 32) | lo_);                                                          \
+    }
+    DSP_SCAN64_STEP(0x111, 0xf)
+    DSP_SCAN64_STEP(0x112, 0xf)
+    DSP_SCAN64_STEP(0x114, 0xf)
+    DSP_SCAN64_STEP(0x118, 0xf)
+    DSP_SCAN64_STEP(0x142, 0xa)
+    DSP_SCAN64_STEP(0x143, 0xc)
+#undef DSP_SCAN64_STEP
+    return v;
+}
+
 // configs[3] glue, all on the device: endpoint frame indices -> what the trim and feature kernels need.
 //   seg[b]      = (int((left  * step) * rate), int((right * step) * rate)) clipped to the clip length
 //                 (endpoint.py:64: fp64 products in that order, truncation; numpy slicing clips at the end;
@@ -767,15 +795,12 @@ __global__ __launch_bounds__(1024) void endpoint_layout_kernel(const int32_t* __
     }
     // inclusive scans of the four per-thread sums: inside each wave with shuffles, across the 16 waves through LDS
     // (two barriers in all; a Hillis-Steele scan over 1024 threads needs twenty)
-    int64_t inc_s = sum_s, inc_f = sum_f;
-    int32_t inc_g = sum_g, inc_t = sum_t;
+    // (DPP row shifts + the two row broadcasts: 6 steps of a few VALU instructions; the __shfl_up form was 36
+    // ds_bpermute round trips, 2 of this kernel's 8.5 us)
+    const int64_t inc_s_ = dsp_wave_scan_i64(sum_s), inc_f_ = dsp_wave_scan_i64(sum_f);
+    int64_t inc_s = inc_s_, inc_f = inc_f_;
+    int32_t inc_g = dsp_wave_scan_i32(sum_g), inc_t = dsp_wave_scan_i32(sum_t);
     const int lane = tid & 63, wv = tid >> 6;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int64_t vs = __shfl_up(inc_s, off, 64), vf = __shfl_up(inc_f, off, 64);
-        const int32_t vg = __shfl_up(inc_g, off, 64), vt = __shfl_up(inc_t, off, 64);
-        if (lane >= off) { inc_s += vs; inc_f += vf; inc_g += vg; inc_t += vt; }
-    }
     if (lane == 63) { part_s[wv] = inc_s; part_f[wv] = inc_f; part_g[wv] = inc_g; part_t[wv] = inc_t; }
     __syncthreads();
     int64_t tot_s = 0, tot_f = 0;
