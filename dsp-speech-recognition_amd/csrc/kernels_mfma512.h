@@ -10,18 +10,23 @@
 // (hi, lo) splitting of the operands, the power spectrum and the delta rows.
 //
 // Work unit: a TILE = 16 consecutive frames of ONE utterance; lane l = (frame n = l & 15, group g = l >> 4).
-// One wave per SIMD (512 registers: the stage-1 results of a tile, 128 packed registers, stay in registers);
-// a wave owns whole utterances, so nothing is exchanged between waves and the delta window never leaves the wave.
+// Two waves per SIMD (256 registers each; the stage-1 results of a tile, 128 packed registers, never leave the register
+// file); a wave owns whole ROW RANGES of utterances (whole utterances, or two ranges per utterance -- a long and a
+// short one per SIMD -- when the batch has fewer utterances than wave slots), so nothing is exchanged between waves and
+// the delta window never leaves the wave.  The kernel is OPT-IN (dsp_debug_use_mfma512 / DSP_MFMA512=1): it does less
+// than half the vector work of the default kernel and runs level with it.
 //  1. staging: the tile's samples (15 S + L, read ONCE per tile through a bounds-checked buffer descriptor: samples
 //     before the utterance and beyond its end read as zero, which IS the reference's zero padding), pre-emphasised,
 //     scaled by a power of two from the tile's largest sample, split into fp16 hi + lo and stored TRANSPOSED in LDS:
-//     plane n2 holds samples 16 r + n2, so a frame's K operand (n1 = 0..31) is contiguous;
+//     plane n2 holds samples 16 r + n2, so a frame's K operand (n1 = 0..31) is contiguous; the image holds 8 of the
+//     16 planes at a time (LDS: 64 KB of stage-1 matrices + 28 KB of mel blocks + 8 KB + 7.5 KB per wave = 160 KB);
 //  2. stage 1: per column n2 six MFMAs (2 row tiles x 3 products) -> (re, im) pairs packed to fp16 hi / lo;
 //  3. a 4 x 4 transpose across the lane groups (v_permlane32_swap / v_permlane16_swap), so that stage 2 finds the
 //     n2 index on the K side;
 //  4. stage 2 per DFT row (six MFMAs), power, bf16 hi / lo, mel blocks (only the non-zero 16 x 32 blocks);
-//  5. log2, DCT * lifter (six MFMAs), scale correction, cepstra into a 32-frame LDS ring;
-//  6. delta / delta-delta from the ring (rows trail the computation by 4 frames), rows copied out contiguously.
+//  5. log2, DCT * lifter (six MFMAs), scale correction, cepstra into a 24-row LDS buffer (8 rows of history);
+//  6. delta / delta-delta from that buffer (rows trail the computation by 4 frames; interior tiles: delta-delta as one
+//     nine-tap filter), rows stored through a bounds-checked descriptor over the range's rows.
 #pragma once
 
 #include "dsp_common.h"
@@ -836,7 +841,7 @@ static inline bool mfma512_applicable(const dsp_plan* p, const BatchGeom& bg, in
     if (bg.uniform_samples <= 0 || bg.seg) return false;
     if (dtype != DSP_WAVE_F32 && dtype != DSP_WAVE_I16) return false;
     if (delta_n < 0 || delta_n > 2) return false;
-    if (bg.uniform_samples * 4 >= ((int64_t)1 << 31) || bg.uniform_frames >= ((int64_t)1 << 24) || (int64_t)bg.n_utt * 64 >= ((int64_t)1 << 31)) return false;
+    if (bg.uniform_samples * 4 >= ((int64_t)1 << 31) || bg.uniform_frames * 64 * 4 >= ((int64_t)1 << 31) || (int64_t)bg.n_utt * 64 >= ((int64_t)1 << 31)) return false;   // 32-bit descriptor ranges and item counts
     if (bg.total_frames < (int64_t)mfma512_device_cus() * M512_WAVES * 16) return false;
     return true;
 }
@@ -851,11 +856,13 @@ static int mfma512_launch_k(const M512Params& P, const void* d_wave, float* d_ou
     const size_t lds = 65536 + (size_t)NWB * 2048 + XTRA + (size_t)WAVES * WAVE_BYTES;
     static_assert(65536 + NWB * 2048 + XTRA + WAVES * WAVE_BYTES <= 163840, "LDS budget");
     auto kern = mfcc512m_kernel<HS, DTYPE, NMT, ND, WAVES>;
-    static bool attr_set = false;   // per instantiation
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};   // per instantiation, one bit per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return DSP_EHIP;
+    if (dev >= 64 || !((attr_set.load() >> dev) & 1ull)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess)
-            return DSP_EHIP;
-        attr_set = true;
+            return 1;   // not served on this device: the caller falls through to the vector-pipe kernels
+        if (dev < 64) attr_set.fetch_or(1ull << dev);
     }
     int grid = mfma512_device_cus();
     const int64_t items = (int64_t)P.n_utt * P.splits;
