@@ -669,12 +669,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void mfcc512m_kernel(M512Par
             auto store_quad = [&](int f, int cq, int part, m512_f4 v) {
                 const int col = 4 * cq;
                 const int32_t off = ((f - o_lo) * Wd + part * C + col) * 4;
+                const m512_u4 u = __builtin_bit_cast(m512_u4, v);   // whole-vector cast (element-wise bit_casts: see m512_buf_load8)
                 if (col + 3 < C) {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(m512_u4, v), rs_o, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(u, rs_o, off, 0, 0);
                 } else {
 #pragma unroll
                     for (int i = 0; i < 3; ++i)
-                        if (col + i < C) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v[i]), rs_o, off + 4 * i, 0, 0);
+                        if (col + i < C) __builtin_amdgcn_raw_buffer_store_b32(u[i], rs_o, off + 4 * i, 0, 0);
                 }
             };
             if constexpr (!ROWS) {

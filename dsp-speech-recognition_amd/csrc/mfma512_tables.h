@@ -40,7 +40,7 @@ struct M512Layout {
     int32_t n_wblocks;                 // mel blocks stored (2 KB each: hi KB, lo KB): always M512_MAX_WBLOCKS
     int32_t wblock_step[M512_MAX_WBLOCKS], wblock_tile[M512_MAX_WBLOCKS];
     int32_t erow;                      // row of the all-ones energy filter (-1: none); filters follow around it
-    int32_t n_mtiles;                  // ceil((M + energy row) / 16)
+    int32_t n_mtiles;                  // row tiles of 16 filters (+ energy row): 2 or 3
     int32_t sa1_log2;                  // A1 carries 2^sa1_log2
     int32_t KR;                        // rows of 16 samples a frame occupies: ceil(min(L, 512) / 16)
     float z_log2_eps;                  // log2(eps) (base.py:26,30)
@@ -136,7 +136,7 @@ static inline int m512_build_tables(int L, int S, int nfft, int M, int C, int ap
     const int Lf = L < 512 ? L : 512;
     const int rows_e = M + (append_energy ? 1 : 0);
     if (rows_e > 48) return -1;
-    lay.n_mtiles = (rows_e + 15) / 16;
+    lay.n_mtiles = rows_e <= 32 ? 2 : 3;   // the kernel is instantiated for two and three row tiles (unused rows: zero weights)
     lay.KR = (Lf + 15) / 16;
     lay.z_log2_eps = (float)log2(2.220446049250313e-16);
     const double PI = 3.14159265358979323846;

@@ -26,11 +26,11 @@ def emul():
     return mfma512_emul
 
 
-@pytest.mark.parametrize('nfilt,L,win', [(40, 400, np.hamming), (26, 400, np.hamming), (40, 320, np.hamming),
+@pytest.mark.parametrize('nfilt,L,win', [(40, 400, np.hamming), (26, 400, np.hamming), (40, 320, np.hamming), (13, 256, np.hanning),
                                           (40, 512, dsp_oracle._ones)])
 def test_tables_reproduce_the_oracle(emul, nfilt, L, win):
     blob, lay = emul.build(L=L, S=160, nfilt=nfilt, win=win)
-    assert lay['n_mtiles'] == (nfilt + 1 + 15) // 16 and len(lay['wblocks']) == (16 if nfilt <= 31 else 14)
+    assert lay['n_mtiles'] == (2 if nfilt + 1 <= 32 else 3) and len(lay['wblocks']) == (16 if nfilt <= 31 else 14)
     for kind in ('white', 'tone', 'ramp', 'siltail'):
         sig = gc.make_signal((kind, 30, 4000))
         cfg = dict(gc.BASE_CFG, nfilt=nfilt, winlen=L / 16000.0, winfunc=win)
