@@ -26,7 +26,7 @@ def emul():
     return mfma512_emul
 
 
-@pytest.mark.parametrize('nfilt,L,win', [(40, 400, np.hamming), (26, 400, np.hamming), (40, 320, np.hamming), (13, 256, np.hanning),
+@pytest.mark.parametrize('nfilt,L,win', [(40, 400, np.hamming), (26, 400, np.hamming), (40, 320, np.hamming), (13, 256, np.hamming),
                                           (40, 512, dsp_oracle._ones)])
 def test_tables_reproduce_the_oracle(emul, nfilt, L, win):
     blob, lay = emul.build(L=L, S=160, nfilt=nfilt, win=win)
