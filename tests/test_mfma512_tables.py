@@ -58,3 +58,24 @@ def test_plans_the_kernel_does_not_serve_are_refused(emul):
     assert rc(nfilt=64) == -1          # more rows than three tiles of 16
     assert rc(S=200) == -1             # hop not a multiple of 16 samples
     assert rc(lowfreq=3000) == -3      # filters of the lowest tile reach beyond the lowest quarter of the spectrum
+
+
+def test_host_fp16_rounding_is_ieee(emul):
+    """The table builder's own fp32 -> fp16 conversion (round to nearest even, subnormals kept) against NumPy's, over
+    normals, subnormals, ties, the overflow edge and signed zeros."""
+    import ctypes as C
+    lib = C.CDLL(SO)
+    lib.m512_half.restype = C.c_uint16
+    lib.m512_half.argtypes = [C.c_float]
+    rng = np.random.default_rng(1)
+    xs = np.concatenate([
+        rng.standard_normal(2000) * 10.0 ** rng.uniform(-9, 5, 2000),
+        np.float32(2.0) ** np.arange(-28, 17),
+        (1.0 + np.arange(0, 64) / 2048.0) * 2.0 ** -3,               # ties and near-ties between fp16 neighbours
+        np.arange(0, 40) * 2.0 ** -25,                                # the subnormal grid and its half steps
+        [0.0, -0.0, 65504.0, 65519.9, 65520.0, 1e6, -1e6, 6.1e-5, 5.96e-8, 2.98e-8, 2.9e-8],
+    ]).astype(np.float32)
+    with np.errstate(over='ignore'):
+        want = xs.astype(np.float16).view(np.uint16)
+    got = np.array([lib.m512_half(float(x)) for x in xs], np.uint16)
+    assert np.array_equal(got, want), [(float(x), hex(g), hex(w)) for x, g, w in zip(xs, got, want) if g != w][:5]
