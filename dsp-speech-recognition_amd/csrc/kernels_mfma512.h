@@ -43,16 +43,10 @@ typedef float m512_f2 __attribute__((ext_vector_type(2)));
 typedef __bf16 m512_b2 __attribute__((ext_vector_type(2)));
 
 #define M512_WAVES 8
-#ifndef M512_PREFETCH
-#define M512_PREFETCH 0       // 1: request the next tile's samples after stage 2 (spills 71 registers: measured slower)
-#endif
 #ifndef M512_AHEAD
 #define M512_AHEAD 1          // stage 1: operand columns in flight (2: +1.5 %, 6 spilled registers)
 #endif
 #define M512_NBUF (M512_AHEAD + 1)
-#ifndef M512_FETCH_SLOT
-#define M512_FETCH_SLOT 11   // stage-2 slot after which the next tile's samples are requested
-#endif
 // Lanes of a wave hand data to each other through LDS (the LDS queue of a wave is in order).  hipcc reasons per
 // lane: a load whose address it can prove different from an earlier store's IN THE SAME LANE may be hoisted above
 // that store -- this keeps program order at the hand-over points.
@@ -366,7 +360,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void mfcc512m_kernel(M512Par
             // stage 2, so every tile requests its samples here and the other wave of the SIMD computes meanwhile (any
             // later request point spills, and a spill reload waits for the outstanding sample loads).  One wave per
             // SIMD (512 registers): the next tile's samples are requested right after stage 1, below.
-            if ((WAVES == 8 && !M512_PREFETCH) || j == 0) fetch(t0);
+            if (WAVES == 8 || j == 0) fetch(t0);
             M512_STAMP(0);
             // ---------------------------------------------------------------- 1. scale of the tile
             float mx = fmaxf(fabsf(pa[0][0]), fabsf(pa[1][0]));
@@ -619,14 +613,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void mfcc512m_kernel(M512Par
 #endif
             M512_STAMP(4);
 
-            // The stage-1 registers are dead: the next tile's samples travel through the log / DCT / delta phase.  The
-            // scheduling barriers keep hipcc from pulling the loads up into stage 2, where their 54 destination registers
-            // do not fit (it did: 77 spilled registers, and a spill reload then waits for the sample loads).
-            if constexpr (M512_PREFETCH) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (j + 1 < J) fetch(t0 + 16);
-                __builtin_amdgcn_sched_barrier(0);
-            }
             // ---------------------------------------------------------------- 5. log2, DCT * lifter, correction
             m512_h8 dmt[2][2];
 #pragma unroll
