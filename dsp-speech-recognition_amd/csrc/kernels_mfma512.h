@@ -774,12 +774,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void mfcc512m_kernel(M512Par
 thread_local int g_use_mfma512 = -1;   // -1: follow the environment
 static inline bool mfma512_enabled() {
     if (g_use_mfma512 >= 0) return g_use_mfma512 == 1;
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("DSP_MFMA512");
-        v = (e && e[0] == '1') ? 1 : 0;
-    }
-    return v == 1;
+    static const bool on = [] { const char* e = getenv("DSP_MFMA512"); return e && e[0] == '1'; }();   // read once, thread-safe
+    return on;
 }
 
 static inline int mfma512_plan_init(dsp_plan* p, const dsp_plan_desc* d) {
@@ -812,13 +808,13 @@ static inline void mfma512_plan_free(dsp_plan* p) {
 }
 
 static inline int mfma512_device_cus() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
+    // (one device model per process: the first device asked answers for all)
+    static const int cus = [] {
+        int dev = 0, n = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        return n > 0 ? n : 256;
+    }();
     return cus;
 }
 
@@ -880,20 +876,18 @@ static inline int mfma512_launch(const dsp_plan* p, const void* d_wave, int dtyp
     P.n_utt = bg.n_utt;
     P.samples = bg.uniform_samples;
     P.frames = bg.uniform_frames;
-    {
-        static int stg = -1;
-        if (stg < 0) { const char* e = getenv("DSP_M512_STAGGER"); stg = e ? atoi(e) : 2; }
-        P.stagger = stg;
-    }
-    static int waves = 0;
-    if (waves == 0) { const char* e = getenv("DSP_M512_WAVES"); waves = (e && atoi(e) == 4) ? 4 : 8; }
+    // A/B knobs, read once (function-local statics: initialised thread-safely)
+    static const int stg = [] { const char* e = getenv("DSP_M512_STAGGER"); return e ? atoi(e) : 2; }();
+    static const int waves = [] { const char* e = getenv("DSP_M512_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
+    static const int forced_splits = [] { const char* e = getenv("DSP_M512_SPLITS"); return e ? atoi(e) : 0; }();
+    P.stagger = stg < 0 ? 0 : (stg > 64 ? 64 : stg);
     // fewer utterances than wave slots: every utterance is cut into row ranges (each range recomputes 8 + 4 frames
     // of its neighbours for the delta windows), as many as keep a range at two tiles or more
     {
         const int64_t slots = (int64_t)mfma512_device_cus() * waves;
         int splits = 1;
         while ((int64_t)bg.n_utt * splits < slots && bg.uniform_frames / (splits + 1) >= 32 && splits < 64) ++splits;
-        if (const char* e = getenv("DSP_M512_SPLITS")) splits = atoi(e) > 0 ? atoi(e) : splits;
+        if (forced_splits > 0 && forced_splits <= 64) splits = forced_splits;
         P.splits = splits;
     }
     const int nmt = mp->lay.n_mtiles;
