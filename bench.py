@@ -214,8 +214,8 @@ def other_paths(dev):
     lib = nat.load()
     st = torch.cuda.current_stream(dev).cuda_stream
 
-    def timed(fn, reps=30):
-        for _ in range(5):
+    def timed(fn, reps=200):
+        for _ in range(10):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(dev)
