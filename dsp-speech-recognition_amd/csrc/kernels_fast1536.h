@@ -34,6 +34,7 @@
 #define F1536_PART_STRIDE F1536_PS_STRIDE   // partial sums overwrite the head of each frame's (dead) spectrum row
 #ifndef F1536_WAVES
 #define F1536_WAVES 8
+#define F1536_R3_ROW 164       // floats per column row of the radix-3 table (== 36 mod 64: conflict-free b128 rows)
 #endif
 
 struct F1536Params {
@@ -262,8 +263,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mfcc1536_kernel(F1536Params P, 
             *reinterpret_cast<float4*>(smem + i) = *reinterpret_cast<const float4*>(P.tables + i);
         __syncthreads();
     }
-    const float* s_win = smem;
-    const float2* s_w3 = reinterpret_cast<const float2*>(smem + P.off_w3);
+    const float* s_r3 = smem;   // radix-3 step: one row of F1536_R3_ROW floats per column c (window + W1536 twiddles, see host side)
     const float2* s_tw = reinterpret_cast<const float2*>(smem + P.off_tw);
     const float* s_dct = smem + P.off_dct;
     const float* s_melw = smem + P.off_melw;
@@ -368,19 +368,27 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mfcc1536_kernel(F1536Params P, 
         cpx y1[32];
         {
             const float* xp = wbuf + d + f * P.S + c;
-            const float* wp = s_win + c;
-            const float2* w3p = s_w3 + c;
+            // the column's window values and twiddles come as 40 conflict-free b128 reads of its own table row (they were
+            // 96 + 32 narrow reads at a stride of 16 floats): per four rows n1, [w(m) x4 | w(m + 512) x4 | w(m + 1024) x4 |
+            // W1536^m x4 (re, im)], m = 16 n1 + c
+            const float4* rp = reinterpret_cast<const float4*>(s_r3 + c * F1536_R3_ROW);
 #pragma unroll
-            for (int n1 = 0; n1 < 32; ++n1) {
-                const float a = xp[16 * n1] * wp[16 * n1];
-                const float b = xp[512 + 16 * n1] * wp[512 + 16 * n1];
-                const float e = xp[1024 + 16 * n1] * wp[1024 + 16 * n1];
-                const float sbe = b + e;
-                y0[n1] = a + sbe;
-                const float tr = fmaf(-0.5f, sbe, a);                     // Re(a + W3 b + W3^2 e)
-                const float ti = 0.86602540378443864676f * (e - b);        // Im(...)
-                const float2 w = w3p[16 * n1];                             // W1536^(16 n1 + c)
-                y1[n1] = {fmaf(tr, w.x, -ti * w.y), fmaf(tr, w.y, ti * w.x)};
+            for (int q = 0; q < 8; ++q) {
+                const float4 wa = rp[5 * q], wb = rp[5 * q + 1], we = rp[5 * q + 2], t0 = rp[5 * q + 3], t1 = rp[5 * q + 4];
+                const float wav[4] = {wa.x, wa.y, wa.z, wa.w}, wbv[4] = {wb.x, wb.y, wb.z, wb.w}, wev[4] = {we.x, we.y, we.z, we.w};
+                const float wx[4] = {t0.x, t0.z, t1.x, t1.z}, wy[4] = {t0.y, t0.w, t1.y, t1.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int n1 = 4 * q + k;
+                    const float a = xp[16 * n1] * wav[k];
+                    const float b = xp[512 + 16 * n1] * wbv[k];
+                    const float e = xp[1024 + 16 * n1] * wev[k];
+                    const float sbe = b + e;
+                    y0[n1] = a + sbe;
+                    const float tr = fmaf(-0.5f, sbe, a);                     // Re(a + W3 b + W3^2 e)
+                    const float ti = 0.86602540378443864676f * (e - b);        // Im(...)
+                    y1[n1] = {fmaf(tr, wx[k], -ti * wy[k]), fmaf(tr, wy[k], ti * wx[k])};   // times W1536^(16 n1 + c)
+                }
             }
         }
         F512_FENCE();
@@ -625,7 +633,21 @@ static inline int fast1536_plan_init(dsp_plan* p, const dsp_plan_desc* d, const 
         }
     }
     auto pad64 = [](size_t n) { return (n + 63) / 64 * 64; };
-    const size_t o_w3 = 1536, o_tw = o_w3 + w3.size(), o_dct = o_tw + tw.size();
+    // radix-3 table: row c (F1536_R3_ROW = 164 floats: 36 c mod 64 runs over the 16 bank quads, so the 16 columns of a b128
+    // lane group never meet on a bank), 8 chunks of 20 floats for rows n1 = 4 q .. 4 q + 3
+    std::vector<float> r3((size_t)16 * F1536_R3_ROW, 0.f);
+    for (int c = 0; c < 16; ++c)
+        for (int q = 0; q < 8; ++q)
+            for (int k = 0; k < 4; ++k) {
+                const int m = 16 * (4 * q + k) + c;
+                float* row = r3.data() + (size_t)c * F1536_R3_ROW + 20 * q;
+                row[k] = win[m];
+                row[4 + k] = win[512 + m];
+                row[8 + k] = win[1024 + m];
+                row[12 + 2 * k] = w3[2 * m];
+                row[13 + 2 * k] = w3[2 * m + 1];
+            }
+    const size_t o_w3 = 0, o_tw = pad64(r3.size()), o_dct = o_tw + tw.size();
     const size_t o_melw = pad64(o_dct + dct.size()), o_mels = o_melw + melw.size();
     const size_t o_pidx = pad64(o_mels + mels.size());
     const size_t total = pad64(o_pidx + pidx.size());
@@ -641,8 +663,7 @@ static inline int fast1536_plan_init(dsp_plan* p, const dsp_plan_desc* d, const 
         return DSP_OK;
     }
     std::vector<float> blob(total, 0.f);
-    memcpy(blob.data(), win.data(), 1536 * 4);
-    memcpy(blob.data() + o_w3, w3.data(), w3.size() * 4);
+    memcpy(blob.data(), r3.data(), r3.size() * 4);
     memcpy(blob.data() + o_tw, tw.data(), tw.size() * 4);
     memcpy(blob.data() + o_dct, dct.data(), dct.size() * 4);
     memcpy(blob.data() + o_melw, melw.data(), melw.size() * 4);
