@@ -29,12 +29,12 @@
 #define F1536_PS_STRIDE 776    // 769 bins + padding; == 8 (mod 64)
 #define F1536_XSTRIDE 544      // exchange buffer per frame: 16 rows x 32 floats + 32 (bank offset)
 #define F1536_MAX_NI 4
+#define F1536_R3_ROW 164       // floats per column row of the radix-3 table (== 36 mod 64: conflict-free b128 rows)
 #define F1536_SLOTS 64         // mel work items per wave (one per lane)
 #define F1536_PIECES 8         // a filter is cut into at most this many slots
 #define F1536_PART_STRIDE F1536_PS_STRIDE   // partial sums overwrite the head of each frame's (dead) spectrum row
 #ifndef F1536_WAVES
 #define F1536_WAVES 8
-#define F1536_R3_ROW 164       // floats per column row of the radix-3 table (== 36 mod 64: conflict-free b128 rows)
 #endif
 
 struct F1536Params {
@@ -210,7 +210,7 @@ __device__ __forceinline__ void f1536_rfft512(const float (&r)[32], float* __res
 }
 
 template <int NI, int NC, int NSTAGE, int DTYPE, int WAVES, bool RAGGED>
-__global__ __launch_bounds__(64 * WAVES, 2) void mfcc1536_kernel(F1536Params P, BatchGeom bg,
+__global__ __launch_bounds__(64 * WAVES, (WAVES > 8 ? 3 : 2)) void mfcc1536_kernel(F1536Params P, BatchGeom bg,
                                                                  const void* __restrict__ wave,
                                                                  float* __restrict__ out, int64_t ld_out) {
     extern __shared__ __attribute__((aligned(256))) float smem_f[];
