@@ -38,6 +38,7 @@ typedef _Float16 m512_h8 __attribute__((ext_vector_type(8)));
 typedef __bf16 m512_b8 __attribute__((ext_vector_type(8)));
 typedef float m512_f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t m512_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t m512_u2 __attribute__((ext_vector_type(2)));
 typedef _Float16 m512_h2 __attribute__((ext_vector_type(2)));
 typedef float m512_f2 __attribute__((ext_vector_type(2)));
 typedef __bf16 m512_b2 __attribute__((ext_vector_type(2)));
@@ -223,10 +224,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void mfcc512m_kernel(M512Par
     uint8_t* const sA2p = m512_smem + 65536 + NWB * 2048;
     uint8_t* const sDm = sA2p + 4096;
     uint8_t* const sWave = m512_smem + 65536 + NWB * 2048 + XTRA + wv * WAVE_BYTES;
-    uint8_t* const imgHi = sWave;
-    uint8_t* const imgLo = sWave + IMG_BYTES;
+    // the image interleaves the two fp16 parts: 8 bytes per ROW PAIR (2 r, 2 r + 1) = [hi(2 r), hi(2 r + 1), lo(2 r), lo(2 r + 1)],
+    // 96 pairs = 768 bytes per plane -- a frame's K octet is four 8-byte aligned ds_read_b64 (hi dword, lo dword) instead
+    // of eight ds_read_b32, and a staged row pair one ds_write_b64 instead of two ds_write_b32
+    constexpr int PLANE = PS * 4;
+    uint8_t* const img = sWave;
     float* const cb = reinterpret_cast<float*>(sWave + 2 * IMG_BYTES);   // cepstra of frames t0 - 8 .. t0 + 15
-    float* const db = reinterpret_cast<float*>(imgHi);                    // deltas (edge tiles only): over the image,
+    float* const db = reinterpret_cast<float*>(img);                      // deltas (edge tiles only): over the image,
                                                                           // dead between stage 1 and the next staging
     const int g = lane >> 4, n = lane & 15;
     const int C = P.C;
@@ -327,13 +331,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void mfcc512m_kernel(M512Par
     for (int i = 0; i < 4; ++i) rowsum[i] = reinterpret_cast<const float*>(P.tables + P.lay.off_rowsum)[4 * g + i];
     __syncthreads();
 
-    // the lane's K octet of plane 0 as LDS pointers: constant offsets fold into the ds_read_b32's offset field, and
-    // volatile keeps hipcc from pairing neighbours into ds_read2_b32 (twice the LDS cycles per byte; the octet starts
-    // at a 4-byte boundary only, so wider reads are not available)
-    typedef __attribute__((address_space(3))) const volatile uint32_t* lds_cvu32;
-    const uint32_t b_loff = 2u * (uint32_t)(HS * n + 8 * g);
-    const lds_cvu32 bHi = reinterpret_cast<lds_cvu32>((uint32_t)reinterpret_cast<uintptr_t>(imgHi + b_loff));
-    const lds_cvu32 bLo = reinterpret_cast<lds_cvu32>((uint32_t)reinterpret_cast<uintptr_t>(imgLo + b_loff));
+    // the lane's K octet of plane 0 as an LDS pointer: constant offsets fold into the ds_read_b64's offset field, and
+    // volatile keeps hipcc from pairing neighbours into ds_read2_b64 (twice the LDS cycles per byte); a frame starts on
+    // a row-pair boundary (hop 160 = 10 rows per plane), i.e. 8-byte aligned in the interleaved image -- not 16
+    const uint32_t b_loff = 2u * (uint32_t)(HS * n + 8 * g);   // 2 bytes per row of ONE part: the image has twice that
+    typedef __attribute__((address_space(3))) const volatile m512_u2* lds_cvu64;
+    const lds_cvu64 bB = reinterpret_cast<lds_cvu64>((uint32_t)reinterpret_cast<uintptr_t>(img + 2 * b_loff));
     const float cpre = P.preemph;
 
 #ifdef M512_STAMPS
@@ -422,17 +425,18 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void mfcc512m_kernel(M512Par
                 for (int e = 0; e < 8; ++e) {
                     uint32_t hh, ll;
                     m512_split_f16(ya[e], ya[8 + e], hh, ll);
-                    *reinterpret_cast<uint32_t*>(imgHi + 2 * (e * PS) + 4 * lane) = hh;
-                    *reinterpret_cast<uint32_t*>(imgLo + 2 * (e * PS) + 4 * lane) = ll;
+                    *reinterpret_cast<m512_u2*>(img + e * PLANE + 8 * lane) = m512_u2{hh, ll};
                 }
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     uint32_t hh, ll;
                     m512_split_f16(yb[e], yb[e + 1], hh, ll);
-                    *reinterpret_cast<uint16_t*>(imgHi + 2 * (e * PS + 128) + 2 * lane) = (uint16_t)hh;
-                    *reinterpret_cast<uint16_t*>(imgHi + 2 * ((e + 1) * PS + 128) + 2 * lane) = (uint16_t)(hh >> 16);
-                    *reinterpret_cast<uint16_t*>(imgLo + 2 * (e * PS + 128) + 2 * lane) = (uint16_t)ll;
-                    *reinterpret_cast<uint16_t*>(imgLo + 2 * ((e + 1) * PS + 128) + 2 * lane) = (uint16_t)(ll >> 16);
+                    // row 128 + l: pair 64 + (l >> 1), half l & 1
+                    uint8_t* const q0 = img + e * PLANE + 8 * (64 + (lane >> 1)) + 2 * (lane & 1);
+                    *reinterpret_cast<uint16_t*>(q0) = (uint16_t)hh;
+                    *reinterpret_cast<uint16_t*>(q0 + PLANE) = (uint16_t)(hh >> 16);
+                    *reinterpret_cast<uint16_t*>(q0 + 4) = (uint16_t)ll;
+                    *reinterpret_cast<uint16_t*>(q0 + PLANE + 4) = (uint16_t)(ll >> 16);
                 }
             };
             // the operands of column n2 + M512_AHEAD are requested while the products of column n2 run (the compiler pulls
@@ -443,8 +447,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void mfcc512m_kernel(M512Par
                 constexpr int sl = n2 % M512_NBUF, pl = n2 & 7;
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    bh[sl][d] = bHi[(2 * pl * PS + 4 * d) / 4];
-                    bl[sl][d] = bLo[(2 * pl * PS + 4 * d) / 4];
+                    const m512_u2 hl = bB[(pl * PLANE + 8 * d) / 8];
+                    bh[sl][d] = hl[0];
+                    bl[sl][d] = hl[1];
                 }
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
