@@ -24,6 +24,7 @@ struct dsp_plan {
     void* d_fast;           // tables of the specialised NFFT=512 kernel (NULL if not applicable)
     void* d_fast1536;       // tables of the specialised NFFT=1536 kernel (NULL if not applicable)
     void* d_mfma;           // tables of the matrix-pipe NFFT=512 kernel, kernels_mfma512.h (NULL if not applicable)
+    void* d_mfmat;          // tables of its frame-per-product form, kernels_mfma512t.h (NULL if not applicable)
     int device;
 };
 

@@ -14,6 +14,7 @@
 #include "kernels_fast512.h"
 #include "kernels_fast1536.h"
 #include "kernels_mfma512.h"
+#include "kernels_mfma512t.h"
 #include "kernels_vad.h"
 #include "kernels_pitch.h"
 
@@ -158,11 +159,11 @@ int dsp_debug_force_generic(int on) {
 }
 
 int dsp_debug_use_mfma512(int on) {
-    g_use_mfma512 = on < 0 ? -1 : (on ? 1 : 0);
+    g_use_mfma512 = on < 0 ? -1 : (on > 2 ? 1 : on);
     return DSP_OK;
 }
 
-int dsp_plan_has_mfma512(const dsp_plan* plan) { return plan && plan->d_mfma ? 1 : 0; }
+int dsp_plan_has_mfma512(const dsp_plan* plan) { return plan ? (plan->d_mfma ? 1 : 0) | (plan->d_mfmat ? 2 : 0) : 0; }
 
 int dsp_debug_pool_stats(long long* n_buffers, long long* bytes) {
     dsp_workspace_pool().stats(n_buffers, bytes);
@@ -181,6 +182,22 @@ int dsp_debug_read_stamps(unsigned long long* out, int n) {
     }
     std::fill(h.begin(), h.end(), 0u);
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(f512_stamp_sum), h.data(), h.size() * 4));
+    return DSP_OK;
+}
+#endif
+
+#ifdef M512T_STAMPS
+// diagnostic builds only: per-phase shader-clock sums of mfcc512t_kernel (not declared in the public header)
+int dsp_debug_read_stamps_m512t(unsigned long long* out, int n) {
+    static std::vector<unsigned int> h(M512T_NSTAMP * 4096);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(m512t_stamp_sum), h.size() * 4));
+    for (int i = 0; i < n && i < M512T_NSTAMP; ++i) {
+        out[i] = 0;
+        for (int w = 0; w < 4096; ++w) out[i] += h[(size_t)w * M512T_NSTAMP + i];
+    }
+    std::fill(h.begin(), h.end(), 0u);
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(m512t_stamp_sum), h.data(), h.size() * 4));
     return DSP_OK;
 }
 #endif
@@ -332,6 +349,7 @@ int dsp_plan_create(const dsp_plan_desc* d, dsp_plan** out) {
     if (rc == DSP_OK) rc = fast512_plan_init(p, d, off.data());
     if (rc == DSP_OK && d->nfilt > 0 && d->numcep > 0) rc = fast1536_plan_init(p, d, off.data());
     if (rc == DSP_OK && d->nfilt > 0 && d->numcep > 0 && p->d_fast) rc = mfma512_plan_init(p, d);
+    if (rc == DSP_OK && d->nfilt > 0 && d->numcep > 0 && p->d_fast) rc = mfma512t_plan_init(p, d);
     if (rc != DSP_OK) { dsp_plan_destroy(p); return rc; }
     *out = p;
     return DSP_OK;
@@ -344,6 +362,7 @@ int dsp_plan_destroy(dsp_plan* p) {
     fast512_plan_free(p);
     fast1536_plan_free(p);
     mfma512_plan_free(p);
+    mfma512t_plan_free(p);
     delete p;
     return DSP_OK;
 }
@@ -419,6 +438,11 @@ static int features_batch_impl(const dsp_plan* plan, const void* d_wave, int wav
     if (uniform_samples > 0 && bg.uniform_frames * n_utt != n_frames_total)
         return fail(DSP_EINVAL, "n_frames_total %lld != n_utt*T (%d*%lld)", (long long)n_frames_total, n_utt, (long long)bg.uniform_frames);
     hipStream_t st = (hipStream_t)stream;
+    if (out_kind == DSP_OUT_MFCC && !g_force_generic && !pre && mfma512t_applicable(plan, bg, wave_dtype, 0)) {
+        const int mrc = mfma512t_launch(plan, d_wave, wave_dtype, bg, 0, d_out, ld_out, st);   // dense batches: matrix-pipe kernel, frame per product
+        if (mrc == DSP_OK) return DSP_OK;
+        if (mrc < 0) return fail(mrc, "matrix-pipe MFCC kernel launch failed");
+    }
     if (out_kind == DSP_OUT_MFCC && !g_force_generic && !pre && mfma512_applicable(plan, bg, wave_dtype, 0)) {
         const int mrc = mfma512_launch(plan, d_wave, wave_dtype, bg, 0, d_out, ld_out, st);   // dense batches: matrix-pipe kernel
         if (mrc == DSP_OK) return DSP_OK;
@@ -532,6 +556,11 @@ int dsp_mfcc_delta_batch(const dsp_plan* plan, const void* d_wave, int wave_dtyp
         if (uniform_frames * n_utt != n_frames_total)
             return fail(DSP_EINVAL, "n_frames_total %lld != n_utt*T (%d*%lld)", (long long)n_frames_total, n_utt, (long long)uniform_frames);
         const BatchGeom fbg = make_geom(nullptr, nullptr, n_utt, n_frames_total, uniform_samples, plan->L, plan->S);
+        if (mfma512t_applicable(plan, fbg, wave_dtype, delta_n)) {
+            const int mrc = mfma512t_launch(plan, d_wave, wave_dtype, fbg, delta_n, d_out, 3 * (int64_t)C, st);
+            if (mrc == DSP_OK) return DSP_OK;
+            if (mrc < 0) return fail(mrc, "matrix-pipe MFCC + delta kernel launch failed");
+        }
         if (mfma512_applicable(plan, fbg, wave_dtype, delta_n)) {
             const int mrc = mfma512_launch(plan, d_wave, wave_dtype, fbg, delta_n, d_out, 3 * (int64_t)C, st);
             if (mrc == DSP_OK) return DSP_OK;

@@ -777,11 +777,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void mfcc512m_kernel(M512Par
 // The matrix-pipe kernel is an opt-in path (measured slower than the vector-pipe kernel at this stage):
 // DSP_MFMA512=1 in the environment, or dsp_debug_use_mfma512(1) for the calling thread.
 thread_local int g_use_mfma512 = -1;   // -1: follow the environment
-static inline bool mfma512_enabled() {
-    if (g_use_mfma512 >= 0) return g_use_mfma512 == 1;
-    static const bool on = [] { const char* e = getenv("DSP_MFMA512"); return e && e[0] == '1'; }();   // read once, thread-safe
-    return on;
+// 0: vector-pipe kernels; 1: this kernel (16 frames per product); 2: kernels_mfma512t.h (one frame per product)
+static inline int mfma512_mode() {
+    if (g_use_mfma512 >= 0) return g_use_mfma512;
+    static const int env = [] { const char* e = getenv("DSP_MFMA512"); return e && (e[0] == '1' || e[0] == '2') ? e[0] - '0' : 0; }();   // read once, thread-safe
+    return env;
 }
+static inline bool mfma512_enabled() { return mfma512_mode() == 1; }
 
 static inline int mfma512_plan_init(dsp_plan* p, const dsp_plan_desc* d) {
     p->d_mfma = nullptr;
@@ -828,6 +830,7 @@ static inline bool mfma512_applicable(const dsp_plan* p, const BatchGeom& bg, in
     if (!p->d_mfma || !mfma512_enabled()) return false;
     if (bg.uniform_samples <= 0 || bg.seg) return false;
     if (dtype != DSP_WAVE_F32 && dtype != DSP_WAVE_I16) return false;
+    if (dtype == DSP_WAVE_I16 && (bg.uniform_samples & 1)) return false;   // dword range checks: an odd int16 utterance would lose its last sample
     if (delta_n < 0 || delta_n > 2) return false;
     if (bg.uniform_samples * 4 >= ((int64_t)1 << 31) || bg.uniform_frames * 64 * 4 >= ((int64_t)1 << 31) || (int64_t)bg.n_utt * 64 >= ((int64_t)1 << 31)) return false;   // 32-bit descriptor ranges and item counts
     if (bg.total_frames < (int64_t)mfma512_device_cus() * M512_WAVES * 16) return false;

@@ -57,7 +57,7 @@ struct M512TLayout {
     int8_t wblock_step[M512T_MAX_WBLOCKS], wblock_tile[M512T_MAX_WBLOCKS];   // step 0..7: packets 8 s .. 8 s + 7; 8: column 0
     int32_t pattern;                   // which (bin range, row tile) blocks the kernel multiplies: m512t_pattern_has
     int32_t erow;                      // row of the all-ones energy filter (-1: none)
-    int32_t n_mtiles;                  // row tiles of 16 filters (+ energy row): 1, 2 or 3
+    int32_t n_mtiles;                  // row tiles of 16 filters (+ energy row): 2 or 3
     float z_log2_eps;                  // log2(eps) (base.py:26,30)
 };
 
@@ -71,7 +71,7 @@ static inline int m512t_build_tables(int L, int S, int nfft, int M, int C, int a
     const int Lf = L < 512 ? L : 512;
     const int rows_e = M + (append_energy ? 1 : 0);
     if (rows_e > 48) return -1;
-    lay.n_mtiles = (rows_e + 15) / 16;
+    lay.n_mtiles = rows_e <= 32 ? 2 : 3;   // the kernel is instantiated for two and three row tiles (unused rows: zero weights)
     lay.z_log2_eps = (float)log2(2.220446049250313e-16);
     const double PI = 3.14159265358979323846;
     // fp16 range: the tile scale keeps |y| < 2^XBITS, so a stage-1 sum is below 2^XBITS * (largest column sum of |w|)

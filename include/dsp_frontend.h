@@ -107,9 +107,12 @@ int dsp_debug_force_generic(int on);
 /* The matrix-pipe NFFT = 512 kernel (csrc/kernels_mfma512.h: the DFT, the mel filterbank and the DCT of
    sigproc.py:136-158 / base.py:8-32 as fp16 / bf16 (hi, lo) products on v_mfma_f32_16x16x32) is an OPT-IN path for
    dense batches: on = 1 routes the calling thread's dsp_features_batch(MFCC) / dsp_mfcc_delta_batch calls to it when it
-   serves the plan and the batch, 0 keeps them on the vector-pipe kernels, -1 follows the environment (DSP_MFMA512=1). */
+   serves the plan and the batch, 2 to its frame-per-product form (csrc/kernels_mfma512t.h: one register-resident matrix
+   per DFT stage, window and twiddle on the vector pipe), 0 keeps them on the vector-pipe kernels, -1 follows the
+   environment (DSP_MFMA512=1 / 2). */
 int dsp_debug_use_mfma512(int on);
-/* 1 if the plan has tables for that kernel (NFFT = 512, hop 160, <= 47 filters in the supported block pattern) */
+/* bit 0: the plan has tables for kernels_mfma512.h (NFFT = 512, hop 160, <= 47 filters in the supported block pattern);
+   bit 1: for kernels_mfma512t.h (NFFT = 512, hop 160, <= 47 filters) */
 int dsp_plan_has_mfma512(const dsp_plan* plan);
 /* testing aid: device workspaces (index tables, cepstra scratch) the library's pool currently holds */
 int dsp_debug_pool_stats(long long* n_buffers, long long* bytes);

@@ -1,4 +1,5 @@
-"""GPU parity of the matrix-pipe NFFT = 512 kernel (csrc/kernels_mfma512.h, opt-in through dsp_debug_use_mfma512).
+"""GPU parity of the matrix-pipe NFFT = 512 kernels (csrc/kernels_mfma512.h: 16 frames per product, mode 1;
+csrc/kernels_mfma512t.h: one frame per product, mode 2; both selected through dsp_debug_use_mfma512).
 The path replaces sigproc.preemphasis / framesig / powspec and base.fbank / mfcc / delta (sigproc.py:66-98,136-158,
 178-185; base.py:8-32,70-79) for dense batches; the oracle is the checker, the vector-pipe kernel a second opinion."""
 import numpy as np
@@ -16,12 +17,18 @@ TOL = 1e-4
 KINDS = ('white', 'tone', 'harmonic', 'siltail', 'vadf', 'ramp', 'zeros', 'uniform')
 
 
+MODES = (1, 2)
+
+
 class _Mfma:
-    """Routes the calling thread's dense MFCC calls to the matrix-pipe kernel for the duration of a with-block."""
+    """Routes the calling thread's dense MFCC calls to a matrix-pipe kernel for the duration of a with-block."""
+
+    def __init__(self, mode=1):
+        self.mode = mode
 
     def __enter__(self):
         from features import _native as nat
-        nat.check(nat.load().dsp_debug_use_mfma512(1))
+        nat.check(nat.load().dsp_debug_use_mfma512(self.mode))
 
     def __exit__(self, *a):
         from features import _native as nat
@@ -48,9 +55,9 @@ def _plan(**over):
     return FeaturePlan(winfunc=np.hamming, **dict(CFG, **over))
 
 
-def _served(plan):
+def _served(plan, mode=1):
     from features import _native as nat
-    return nat.load().dsp_plan_has_mfma512(plan.plan.handle) == 1
+    return (nat.load().dsp_plan_has_mfma512(plan.plan.handle) >> (mode - 1)) & 1 == 1
 
 
 def _worst(got, fo, waves, cfg, delta_n, idx):
@@ -77,39 +84,42 @@ def _worst(got, fo, waves, cfg, delta_n, idx):
     ('numcep3_nfilt13', dict(numcep=3, nfilt=13), 600, 16000, 2, np.float32),      # one row tile of filters, partial quads
     ('numcep15', dict(numcep=15), 600, 16000, 1, np.float32),
 ])
-def test_matrix_pipe_kernel_vs_oracle(name, over, B, N, delta_n, dtype):
+@pytest.mark.parametrize('mode', MODES)
+def test_matrix_pipe_kernel_vs_oracle(mode, name, over, B, N, delta_n, dtype):
     cfg = dict(CFG, **over)
     plan = _plan(**over)
-    assert _served(plan)
+    assert _served(plan, mode)
     waves = _batch(B, N, dtype=dtype)
-    with _Mfma():
+    with _Mfma(mode):
         got, fo = plan.mfcc_batch(waves, delta_n=delta_n)
     idx = list(range(0, 2 * len(KINDS))) + list(range(2 * len(KINDS), B, max(1, B // 24))) + [B - 1]
-    worst = record('mfma512_' + name, _worst(got, fo, waves, cfg, delta_n, idx))
+    worst = record(('mfma512_' if mode == 1 else 'mfma512t_') + name, _worst(got, fo, waves, cfg, delta_n, idx))
     assert worst <= TOL, worst
 
 
-def test_matrix_pipe_and_vector_pipe_kernels_agree():
+@pytest.mark.parametrize('mode', MODES)
+def test_matrix_pipe_and_vector_pipe_kernels_agree(mode):
     """Two independent implementations of the same path (fp16-split matrix products vs in-register fp32 butterflies)."""
     plan = _plan()
     waves = _batch(1024, 16000, seed=9)
     vec, fo = plan.mfcc_batch(waves, delta_n=2)
-    with _Mfma():
+    with _Mfma(mode):
         mat, fo2 = plan.mfcc_batch(waves, delta_n=2)
     assert np.array_equal(fo, fo2)
     worst = max(normwise(mat[fo[b]:fo[b + 1]], vec[fo[b]:fo[b + 1]]) for b in range(0, 1024, 7))
-    assert record('mfma512_vs_vector_pipe', worst) <= TOL
+    assert record('mfma512_vs_vector_pipe' if mode == 1 else 'mfma512t_vs_vector_pipe', worst) <= TOL
 
 
-def test_matrix_pipe_results_do_not_depend_on_the_batch():
-    """A wave owns whole row ranges of ONE utterance and scales each 16-frame tile by its own largest sample, so an
-    utterance's rows are the same bits whatever surrounds it -- as long as it is cut into the same ranges: the same
+@pytest.mark.parametrize('mode', MODES)
+def test_matrix_pipe_results_do_not_depend_on_the_batch(mode):
+    """A wave owns whole row ranges of ONE utterance and scales each tile (mode 2: half tile) by its own largest sample,
+    so an utterance's rows are the same bits whatever surrounds it -- as long as it is cut into the same ranges: the same
     utterance in two batches of one size, at different positions, next to different neighbours."""
     plan = _plan()
     a = _batch(1024, 16000, seed=21)
     b = a[::-1].copy()
     b[500] = np.nan                                    # a NaN clip must not leak into its neighbours
-    with _Mfma():
+    with _Mfma(mode):
         ra, fo = plan.mfcc_batch(a, delta_n=2)
         rb, _ = plan.mfcc_batch(b, delta_n=2)
     ra = ra.reshape(1024, 99, 39)
@@ -120,33 +130,50 @@ def test_matrix_pipe_results_do_not_depend_on_the_batch():
     assert np.isnan(rb[1023 - 500]).any()
 
 
-def test_plans_outside_the_kernel_fall_back():
-    """More than 47 filters, a hop that is not 160 samples, a filterbank outside the block pattern: the plan carries no
-    matrix-pipe tables and the switch changes nothing."""
+@pytest.mark.parametrize('mode', MODES)
+def test_plans_outside_the_kernel_fall_back(mode):
+    """More than 47 filters, a hop that is not 160 samples, (mode 1) a filterbank outside the block pattern: the plan
+    carries no matrix-pipe tables and the switch changes nothing."""
     waves = _batch(600, 16000, seed=5)
-    for over in (dict(nfilt=64), dict(winstep=0.0125), dict(lowfreq=3000)):
+    for over in (dict(nfilt=64), dict(winstep=0.0125)) + ((dict(lowfreq=3000),) if mode == 1 else ()):
         plan = _plan(**over)
-        assert not _served(plan), over
+        assert not _served(plan, mode), over
         ref, fo = plan.mfcc_batch(waves, delta_n=2)
-        with _Mfma():
+        with _Mfma(mode):
             got, _ = plan.mfcc_batch(waves, delta_n=2)
         assert np.array_equal(got, ref), over
 
 
 @pytest.mark.parametrize('N,B', [(300, 40000), (401, 36000), (1000, 8000), (2965, 2500)])
-def test_short_utterances(N, B):
+@pytest.mark.parametrize('mode', MODES)
+def test_short_utterances(mode, N, B):
     """One frame with zero padding (N < L), two frames, a handful: the first tile is also the last, the delta windows
     clamp on both sides, most of a tile's columns are padding."""
     plan = _plan()
     rng = np.random.default_rng(N)
     waves = (0.25 * rng.standard_normal((B, N))).astype(np.float32)
-    with _Mfma():
+    with _Mfma(mode):
         got, fo = plan.mfcc_batch(waves, delta_n=2)
     idx = list(range(0, B, max(1, B // 40))) + [B - 1]
-    assert record(f'mfma512_short_{N}', _worst(got, fo, waves, CFG, 2, idx)) <= TOL
+    assert record(f'mfma512{"t" if mode == 2 else ""}_short_{N}', _worst(got, fo, waves, CFG, 2, idx)) <= TOL
 
 
-def test_extreme_amplitudes_and_silence():
+@pytest.mark.parametrize('N,B', [(401, 3000), (2966, 2500), (16001, 1024)])
+@pytest.mark.parametrize('mode', MODES)
+def test_int16_lengths_the_descriptor_cannot_read(mode, N, B):
+    """int16 utterances of odd length (and one even, 4 k + 2): the kernels read whole dwords through a bounds-checked
+    descriptor, so an odd length would lose its last sample -- such batches go to the vector-pipe path instead."""
+    plan = _plan()
+    rng = np.random.default_rng(N)
+    waves = np.clip(np.round(3000 * rng.standard_normal((B, N))), -32768, 32767).astype(np.int16)
+    with _Mfma(mode):
+        got, fo = plan.mfcc_batch(waves, delta_n=2)
+    idx = list(range(0, B, max(1, B // 24))) + [B - 1]
+    assert record(f'mfma512{"t" if mode == 2 else ""}_int16_{N}', _worst(got, fo, waves, CFG, 2, idx)) <= TOL
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_extreme_amplitudes_and_silence(mode):
     """The tile scale is a power of two from the tile's largest sample: 1e-30 ... 1e30, exact zeros (the eps path of
     base.py:26,30) and a clip that is silent except for one sample."""
     plan = _plan()
@@ -160,13 +187,14 @@ def test_extreme_amplitudes_and_silence():
     waves[11] = 0.0
     waves[11, 7777] = 1.0
     waves[12, 8000:] = 0.0
-    with _Mfma():
+    with _Mfma(mode):
         got, fo = plan.mfcc_batch(waves, delta_n=2)
     assert np.isfinite(got).all()
-    assert record('mfma512_extremes', _worst(got, fo, waves, CFG, 2, list(range(16)) + [B - 1])) <= TOL
+    assert record('mfma512_extremes' if mode == 1 else 'mfma512t_extremes', _worst(got, fo, waves, CFG, 2, list(range(16)) + [B - 1])) <= TOL
 
 
-def test_random_plans():
+@pytest.mark.parametrize('mode', MODES)
+def test_random_plans(mode):
     """Twenty random plans inside the kernel's envelope (window length and shape, filter count and band, cepstra kept,
     lifter, pre-emphasis, energy swap): wherever the library builds matrix-pipe tables for a plan, the kernel must
     reproduce the oracle; a plan it refuses must fall back without a trace."""
@@ -187,9 +215,9 @@ def test_random_plans():
         from features.batch import FeaturePlan
         plan = FeaturePlan(winfunc=wins[wname], **cfg)
         delta_n = int(rng.integers(0, 3))
-        with _Mfma():
+        with _Mfma(mode):
             got, fo = plan.mfcc_batch(waves, delta_n=delta_n)
-        if nat.load().dsp_plan_has_mfma512(plan.plan.handle) != 1:
+        if not _served(plan, mode):
             ref, _ = plan.mfcc_batch(waves, delta_n=delta_n)
             assert np.array_equal(got, ref), cfg
             continue
@@ -206,5 +234,5 @@ def test_random_plans():
             g = got[fo[b]:fo[b + 1]]
             assert g.shape == ref.shape and np.isfinite(g).all(), (cfg, wname, b)
             worst = max(worst, normwise(g, ref))
-        assert record('mfma512_random_plans', worst) <= TOL, (cfg, wname, delta_n, worst)
+        assert record('mfma512_random_plans' if mode == 1 else 'mfma512t_random_plans', worst) <= TOL, (cfg, wname, delta_n, worst)
     assert served >= 8, served
