@@ -983,4 +983,45 @@ int dsp_endpoint_rule_batch(const double* d_amp_sum, const int32_t* d_zcr, const
     return DSP_OK;
 }
 
+int dsp_acr_gate_batch(const void* d_wave, int wave_dtype, const int64_t* d_sample_offsets,
+                       const int64_t* d_frame_offsets, int32_t n_utt, int64_t n_frames_total, int64_t uniform_samples,
+                       int32_t frame_len, int32_t frame_step, int32_t lag_lo, int32_t lag_hi, double thresh,
+                       uint8_t* d_voiced, void* stream) {
+    if (!d_voiced) return fail(DSP_EINVAL, "dsp_acr_gate_batch: d_voiced is NULL");
+    if (frame_len <= 0 || frame_step <= 0) return fail(DSP_EINVAL, "frame_len / frame_step must be > 0");
+    if (lag_lo < 1 || lag_hi <= lag_lo || lag_hi > frame_len)
+        return fail(DSP_EINVAL, "lags [%d, %d) must lie in [1, frame_len = %d]", lag_lo, lag_hi, frame_len);
+    const size_t lds = (size_t)4 * frame_len * sizeof(double);
+    if (lds > 64 * 1024) return fail(DSP_EINVAL, "frame_len %d too long for the autocorrelation gate (<= 2048)", frame_len);
+    int rc = check_geom(d_wave, wave_dtype, d_sample_offsets, d_frame_offsets, n_utt, n_frames_total, uniform_samples);
+    if (rc != DSP_OK) return rc;
+    BatchGeom bg = make_geom(d_sample_offsets, d_frame_offsets, n_utt, n_frames_total, uniform_samples, frame_len, frame_step);
+    if (uniform_samples > 0 && bg.uniform_frames * n_utt != n_frames_total)
+        return fail(DSP_EINVAL, "n_frames_total %lld != n_utt*T (%d*%lld)", (long long)n_frames_total, n_utt, (long long)bg.uniform_frames);
+    if (n_frames_total <= 0) return DSP_OK;
+    const int64_t blocks = (n_frames_total + 3) / 4;
+    if (blocks > 0x7fffffff) return fail(DSP_EINVAL, "too many frames");
+    hipStream_t st = (hipStream_t)stream;
+    if (wave_dtype == DSP_WAVE_I16)
+        acr_gate_kernel<DSP_WAVE_I16><<<(int)blocks, 256, lds, st>>>(d_wave, bg, frame_len, frame_step, lag_lo, lag_hi, thresh, d_voiced);
+    else
+        acr_gate_kernel<DSP_WAVE_F32><<<(int)blocks, 256, lds, st>>>(d_wave, bg, frame_len, frame_step, lag_lo, lag_hi, thresh, d_voiced);
+    HIP_TRY(hipGetLastError());
+    return DSP_OK;
+}
+
+int dsp_endpoint_rule_acr_batch(const double* d_amp_sum, const int32_t* d_zcr, const uint8_t* d_voiced,
+                                const int64_t* d_frame_offsets, int32_t n_utt, int32_t frame_len, double cfg_frame,
+                                double cfg_step, int32_t* d_endpoints, void* stream) {
+    if (!d_amp_sum || !d_zcr || !d_voiced || !d_frame_offsets || !d_endpoints || n_utt <= 0 || frame_len <= 0)
+        return fail(DSP_EINVAL, "dsp_endpoint_rule_acr_batch: bad arguments");
+    if (!(cfg_frame > 0.0) || !(cfg_step > 0.0)) return fail(DSP_EINVAL, "cfg.frame / cfg.step must be > 0");
+    if (2 * (int)(0.100 / cfg_step) > DSP_MAX_SIL)
+        return fail(DSP_EINVAL, "cfg.step %g gives a silence window > %d frames", cfg_step, DSP_MAX_SIL);
+    endpoint_rule_kernel<<<n_utt, 64, 0, (hipStream_t)stream>>>(
+        d_amp_sum, d_zcr, d_frame_offsets, n_utt, frame_len, cfg_frame, cfg_step, d_endpoints, d_voiced);
+    HIP_TRY(hipGetLastError());
+    return DSP_OK;
+}
+
 }  // extern "C"

@@ -479,10 +479,12 @@ __global__ __launch_bounds__(256) void vad_features_kernel(const void* __restric
 
 // endpoint.amplitude_rule (endpoint.py:133-179, use_acr=False): only the first segment's start and
 // the last segment's end are consumed by basic_endpoint_detection (endpoint.py:43,49).
+// `voiced` (robust_endpoint_detection, endpoint.py:168-170): a segment only grows over frames whose bit is set.
 template <typename AmpT, typename SilT>
 __device__ __forceinline__ void amplitude_rule_dev(AmpT amp, int64_t T, double inv_L, double mh,
                                                    double th, int n_l, int n_r, double sigma, double cfg_frame,
-                                                   SilT sil, int64_t& left, int64_t& right) {
+                                                   SilT sil, int64_t& left, int64_t& right,
+                                                   const uint8_t* __restrict__ voiced = nullptr) {
     int ns = 0;
     const int64_t cl = n_l < T ? n_l : T;                   // amp[:n_l]
     for (int64_t i = 0; i < cl; ++i) sil[ns++] = amp[i] * inv_L;
@@ -515,8 +517,8 @@ __device__ __forceinline__ void amplitude_rule_dev(AmpT amp, int64_t T, double i
             if ((double)(k - j) < T_H) {
                 i = k;
             } else {
-                while (j > 0 && amp[j] * inv_L > M_L) --j;
-                while (k < T && amp[k] * inv_L > M_L) ++k;
+                while (j > 0 && amp[j] * inv_L > M_L && (!voiced || voiced[j])) --j;
+                while (k < T && amp[k] * inv_L > M_L && (!voiced || voiced[k])) ++k;
                 if (!any) { left = j; any = true; }
                 right = k;
                 i = k;
@@ -550,12 +552,17 @@ __device__ __forceinline__ void endpoint_zcr_rule(ZcrT z, int64_t T, int64_t lef
 
 template <typename AmpT, typename ZcrT, typename SilT>
 __device__ __forceinline__ void endpoint_rule_body(AmpT amp, ZcrT z, SilT sil, int64_t T, double inv_L,
-                                                   double cfg_frame, double cfg_step, int32_t* __restrict__ out2) {
+                                                   double cfg_frame, double cfg_step, int32_t* __restrict__ out2,
+                                                   const uint8_t* __restrict__ voiced = nullptr) {
     const int n_sil = (int)(0.100 / cfg_step);              // int(l_sil / cfg.step), endpoint.py:151
     int64_t left = 0, right = T;
-    amplitude_rule_dev(amp, T, inv_L, 0.25, 0.100, n_sil, n_sil, 3.0, cfg_frame, sil, left, right);
-    if (right - left < 50)                                  // endpoint.py:44-45
-        amplitude_rule_dev(amp, T, inv_L, 0.125, 0.100, n_sil, n_sil, 3.0, cfg_frame, sil, left, right);
+    if (voiced) {                                           // robust_endpoint_detection: one pass, mh = 0.5 (endpoint.py:73)
+        amplitude_rule_dev(amp, T, inv_L, 0.5, 0.100, n_sil, n_sil, 3.0, cfg_frame, sil, left, right, voiced);
+    } else {
+        amplitude_rule_dev(amp, T, inv_L, 0.25, 0.100, n_sil, n_sil, 3.0, cfg_frame, sil, left, right);
+        if (right - left < 50)                              // endpoint.py:44-45
+            amplitude_rule_dev(amp, T, inv_L, 0.125, 0.100, n_sil, n_sil, 3.0, cfg_frame, sil, left, right);
+    }
     endpoint_zcr_rule(z, T, left, right, n_sil, cfg_frame, out2);
 }
 
@@ -568,7 +575,10 @@ __global__ __launch_bounds__(64) void endpoint_rule_kernel(const double* __restr
                                                            const int32_t* __restrict__ zcr,
                                                            const int64_t* __restrict__ frame_off, int32_t n_utt,
                                                            int32_t L, double cfg_frame, double cfg_step,
-                                                           int32_t* __restrict__ endpoints) {
+                                                           int32_t* __restrict__ endpoints,
+                                                           // robust_endpoint_detection (endpoint.py:68-92): one bit per frame from
+                                                           // acr_gate_kernel; mh = 0.5, a single pass, growth gated by the bit
+                                                           const uint8_t* __restrict__ voiced = nullptr) {
     __shared__ double s_amp[DSP_RULE_LDS_FRAMES];
     __shared__ int32_t s_zcr[DSP_RULE_LDS_FRAMES];
     __shared__ double s_sil[DSP_MAX_SIL];
@@ -624,7 +634,7 @@ __global__ __launch_bounds__(64) void endpoint_rule_kernel(const double* __restr
             for (int i = 0; i < m; ++i) var += (s_sorted[i] - mean) * (s_sorted[i] - mean);
             const double sd = m > 0 ? sqrt(var / m) : mean;
             const double M_L = mean + 3.0 * sd;
-            const double a1 = mx * 0.25, a2 = mx * 0.125;            // mh, and the retry of endpoint.py:44-45
+            const double a1 = mx * (voiced ? 0.5 : 0.25), a2 = mx * 0.125;   // mh (endpoint.py:73: 0.5 with the gate), and the retry of endpoint.py:44-45
             s_thr[0] = M_L;
             s_thr[1] = (M_L > a1) ? M_L : a1;                         // python max(a, M_L): NaN M_L loses
             s_thr[2] = (M_L > a2) ? M_L : a2;
@@ -639,7 +649,9 @@ __global__ __launch_bounds__(64) void endpoint_rule_kernel(const double* __restr
                 const int i = 64 * w + lane;
                 const bool ok = i < (int)T;
                 const double v = ok ? s_amp[i] : 0.0;
-                const unsigned long long m0 = __ballot(ok && v > M_L), m1 = __ballot(ok && v > M_H1),
+                // with the gate, "amp > M_L" only ever appears as "amp > M_L and voiced" (endpoint.py:168-170)
+                const bool vc = voiced == nullptr || (ok && voiced[base + i] != 0);
+                const unsigned long long m0 = __ballot(ok && v > M_L && vc), m1 = __ballot(ok && v > M_H1),
                                          m2 = __ballot(ok && v >= M_H1), m3 = __ballot(ok && v > M_H2),
                                          m4 = __ballot(ok && v >= M_H2);
                 if (lane == 0) {
@@ -705,13 +717,71 @@ __global__ __launch_bounds__(64) void endpoint_rule_kernel(const double* __restr
                 ++i;
             }
             if (!any) { left = 0; right = T; }
-            if (right - left >= 50) break;                             // endpoint.py:44-45
+            if (right - left >= 50 || voiced != nullptr) break;        // endpoint.py:44-45 (no retry in the robust form)
         }
         endpoint_zcr_rule(s_zcr, T, left, right, n_sil, cfg_frame, endpoints + 2 * b);
     } else {
         if (threadIdx.x != 0) return;
-        endpoint_rule_body(amp, z, s_sil, T, inv_L, cfg_frame, cfg_step, endpoints + 2 * b);
+        endpoint_rule_body(amp, z, s_sil, T, inv_L, cfg_frame, cfg_step, endpoints + 2 * b, voiced ? voiced + base : nullptr);
     }
+}
+
+// The autocorrelation gate of endpoint.robust_endpoint_detection (endpoint.py:142-144 with sigproc.acr,
+// sigproc.py:48-53): frame g is "voiced" when  max_{n in [lag_lo, lag_hi)} (sum_i x[i] x[i+n] / (L - n))  /  (sum_i x[i]^2 / L)
+// exceeds `thresh` (0.55), the frame being the rectangular to_frames frame (sigproc.py:11-19, zero padded).
+// One wavefront per frame; the frame sits in LDS as fp64 (products of fp32 / int16 samples are exact in fp64, so the sums
+// equal NumPy's to the last bits of the additions); lane l takes lags lag_lo + l, + 64, ...: x[i] is a broadcast read,
+// x[i + n] a conflict-free one.  A quotient that is NaN (an all-zero frame: 0 / 0) compares false, as in the reference.
+template <int DTYPE>
+__global__ __launch_bounds__(256) void acr_gate_kernel(const void* __restrict__ wave, BatchGeom bg, int32_t L, int32_t S,
+                                                       int32_t lag_lo, int32_t lag_hi, double thresh,
+                                                       uint8_t* __restrict__ voiced) {
+    extern __shared__ __attribute__((aligned(16))) double acr_smem[];
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* const x = acr_smem + (size_t)wid * L;
+    const int64_t total_frames = bg.uniform_frames > 0 ? bg.total_frames : bg.frame_off[bg.n_utt];
+    const int64_t g = (int64_t)blockIdx.x * 4 + wid;
+    if (g >= total_frames) return;                          // (wave-uniform; no barrier below)
+    int32_t utt;
+    int64_t t, s0, nsamp;
+    dsp_locate(bg, g, utt, t, s0, nsamp);
+    const int64_t first = t * (int64_t)S;
+    double e0 = 0.0;
+    for (int i = lane; i < L; i += 64) {
+        const double v = first + i < nsamp ? (double)dsp_load_sample<DTYPE>(wave, s0 + first + i) : 0.0;
+        x[i] = v;
+        e0 = fma(v, v, e0);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) e0 += __shfl_xor(e0, o, 64);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own LDS stores (one wave per frame: no barrier)
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    double best = nan;                                      // python max(): the first value, then anything greater
+    for (int n = lag_lo + lane; n < lag_hi; n += 64) {
+        double a = nan;
+        if (n < L) {
+            double acc0 = 0.0, acc1 = 0.0;
+            const int m = L - n;
+            int i = 0;
+            for (; i + 1 < m; i += 2) {
+                acc0 = fma(x[i], x[i + n], acc0);
+                acc1 = fma(x[i + 1], x[i + 1 + n], acc1);
+            }
+            if (i < m) acc0 = fma(x[i], x[i + n], acc0);
+            a = (acc0 + acc1) / (double)m;
+        } else if (n == L) {
+            a = nan;                                        // numpy: the sum of an empty product is 0, divided by 0
+        }
+        // (lags beyond L wrap in numpy slicing; no caller's rate / frame length reaches them: rate // 50 < int(0.03 rate))
+        if (a > best || !(best == best)) best = a;
+    }
+    // wave maximum; NaN lanes (no lag) lose to any number
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double other = __shfl_xor(best, o, 64);
+        best = (other > best || !(best == best)) ? other : best;
+    }
+    if (lane == 0) voiced[g] = (best / (e0 / (double)L) > thresh) ? 1 : 0;
 }
 
 // Inclusive prefix sums over the 64 lanes of a wave without LDS: row_shr 1, 2, 4, 8 inside each row of 16 lanes, then

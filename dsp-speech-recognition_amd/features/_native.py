@@ -73,6 +73,8 @@ SIGNATURES = {
     'dsp_vad_features_layout_batch': (C.c_int, [c_vp, c_vp, C.c_int, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     'dsp_trim_scale_batch': (C.c_int, [c_vp, C.c_int, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     'dsp_endpoint_rule_batch': (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_f64, c_f64, c_vp, c_vp]),
+    'dsp_acr_gate_batch': (C.c_int, [c_vp, C.c_int, c_vp, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_f64, c_vp, c_vp]),
+    'dsp_endpoint_rule_acr_batch': (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f64, c_f64, c_vp, c_vp]),
     'dsp_endpoint_layout_batch': (C.c_int, [c_vp, c_vp, c_i32, c_f64, c_f64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'dsp_model_timefeat_batch': (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     'dsp_pitch_scores_batch': (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_vp, c_i32,

@@ -95,11 +95,31 @@ def vad_features(sig, L, S, use_sq=False):
     return d_amp, d_zcr, T
 
 
-def endpoint_rule(d_amp, d_zcr, T, L, cfg_frame, cfg_step):
+def endpoint_rule(d_amp, d_zcr, T, L, cfg_frame, cfg_step, d_voiced=None):
+    """Frame indices (left, right) of one utterance from its amp / zcr rows on the device; with `d_voiced` (one byte
+    per frame from acr_gate) the robust form of endpoint.py:68-92."""
     lib = nat.load()
     d_off = nat.device_array('ep_off', np.array([0, T], dtype=np.int64))
     d_ep = nat.SCRATCH.get('ep_out', 8)
-    nat.check(lib.dsp_endpoint_rule_batch(d_amp.ptr, d_zcr.ptr, d_off.ptr, 1, int(L), float(cfg_frame),
-                                          float(cfg_step), d_ep.ptr, None))
+    if d_voiced is None:
+        nat.check(lib.dsp_endpoint_rule_batch(d_amp.ptr, d_zcr.ptr, d_off.ptr, 1, int(L), float(cfg_frame),
+                                              float(cfg_step), d_ep.ptr, None))
+    else:
+        nat.check(lib.dsp_endpoint_rule_acr_batch(d_amp.ptr, d_zcr.ptr, d_voiced.ptr, d_off.ptr, 1, int(L), float(cfg_frame),
+                                                  float(cfg_step), d_ep.ptr, None))
     ep = d_ep.download((2,), np.int32)
     return int(ep[0]), int(ep[1])
+
+
+def acr_gate(sig, L, S, rate, thresh=0.55):
+    """One byte per frame of one utterance framed at (L, S): the autocorrelation gate of endpoint.py:142-144 (lags
+    rate // 500 .. rate // 50 - 1).  The wave buffer is the one vad_features uploaded (same scratch slot)."""
+    lib = nat.load()
+    wave, dtype = nat.as_wave(_signal_1d(sig))
+    n = wave.shape[0]
+    T = nat.frame_count(n, L, S)
+    d_wave = nat.device_array('wave', wave)
+    d_v = nat.SCRATCH.get('acr_voiced', T)
+    nat.check(lib.dsp_acr_gate_batch(d_wave.ptr, dtype, None, None, 1, T, n, int(L), int(S), int(rate) // 500, int(rate) // 50,
+                                     float(thresh), d_v.ptr, None))
+    return d_v

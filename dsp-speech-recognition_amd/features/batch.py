@@ -185,11 +185,16 @@ class FeaturePlan:
 
 class EndpointPlan:
     """Batched endpoint.basic_endpoint_detection (endpoint.py:34-66) at a fixed (rate, cfg.frame,
-    cfg.step): per-frame amplitude + ZCR and the threshold state machine, all on the device."""
+    cfg.step): per-frame amplitude + ZCR and the threshold state machine, all on the device.
+    robust=True: endpoint.robust_endpoint_detection (endpoint.py:68-92) -- the autocorrelation gate of every
+    frame (dsp_acr_gate_batch) is one more launch and the state machine runs in its gated, single-pass form."""
 
-    def __init__(self, rate=16000, frame=0.03, step=0.01):
+    def __init__(self, rate=16000, frame=0.03, step=0.01, robust=False):
         self.rate, self.frame, self.step = rate, frame, step
         self.L, self.S = int(rate * frame), int(step * rate)  # sigproc.py:19 truncation
+        self.robust = bool(robust)
+        if self.robust and rate // 50 > self.L:
+            raise ValueError('robust endpointing: the gate\'s lags (rate // 50) reach past the frame')
 
     def layout(self, waves, sample_offsets=None):
         return _layout_for(self.L, self.S, waves, sample_offsets)
@@ -207,6 +212,14 @@ class EndpointPlan:
                                                  self.L, self.S, 0, d_amp_sum, d_zcr, st))
         if layout.d_frame is None:  # the rule kernel always takes explicit frame offsets
             layout.d_frame = nat.DeviceBuffer(layout.frame_offsets.nbytes).upload(layout.frame_offsets)
+        if self.robust:
+            d_voiced = nat.SCRATCH.get('ep_voiced', max(1, layout.total_frames))
+            nat.check(lib.dsp_acr_gate_batch(d_wave, wave_dtype, layout.p_sample, layout.p_frame, layout.n_utt,
+                                             layout.total_frames, layout.uniform_samples, self.L, self.S,
+                                             int(self.rate) // 500, int(self.rate) // 50, 0.55, d_voiced.ptr, st))
+            nat.check(lib.dsp_endpoint_rule_acr_batch(d_amp_sum, d_zcr, d_voiced.ptr, layout.d_frame.ptr, layout.n_utt, self.L,
+                                                      float(self.frame), float(self.step), d_endpoints, st))
+            return
         nat.check(lib.dsp_endpoint_rule_batch(d_amp_sum, d_zcr, layout.d_frame.ptr, layout.n_utt, self.L,
                                               float(self.frame), float(self.step), d_endpoints, st))
 

@@ -166,15 +166,19 @@ def basic_endpoint_detection(sig, rate, return_feature=False):
 
 def robust_endpoint_detection(sig, rate):
     """Autocorrelation-gated variant (endpoint.py:68-92): one amplitude-rule pass with mh = 0.5 that
-    only grows a segment over frames whose normalised autocorrelation peak (lags rate/500..rate/50)
-    exceeds 0.55.  Frames, amplitude and ZCR come from the GPU; the gate is evaluated in fp64 on the
-    handful of frames the rule actually visits (scalar control flow, as in the reference)."""
-    frames = to_frames(sig, rate, cfg.frame, step=cfg.step)
-    amp = get_amplitude(frames)
-    seg = amplitude_rule(amp, 0.5, frames=frames, use_acr=True, rate=rate)
-    left, right = seg[0][0], seg[-1][1]
-    zcr = get_zcr(frames)
-    left2, right2 = zcr_rule(zcr, left, right)
-    if right2 - left2 < 50:
-        left2, right2 = 0, len(frames)
-    return int(left2 * cfg.step * rate), int(right2 * cfg.step * rate)
+    only grows a segment over frames whose normalised autocorrelation peak (lags rate//500 .. rate//50 - 1)
+    exceeds 0.55.  A batch of one on the device: amplitude + ZCR (dsp_vad_features_batch), the gate of every
+    frame (dsp_acr_gate_batch, fp64 sums) and the state machine with the gate as one more bit per frame
+    (dsp_endpoint_rule_acr_batch); two result words come back.  Batches: features.batch.EndpointPlan(robust=True)."""
+    L, S = int(rate * cfg.frame), int(cfg.step * rate)
+    if rate // 50 > L:     # the gate's lags reach past the frame: no caller's cfg does this; the list form still serves it
+        frames = to_frames(sig, rate, cfg.frame, step=cfg.step)
+        seg = amplitude_rule(get_amplitude(frames), 0.5, frames=frames, use_acr=True, rate=rate)
+        left2, right2 = zcr_rule(get_zcr(frames), seg[0][0], seg[-1][1])
+        if right2 - left2 < 50:
+            left2, right2 = 0, len(frames)
+        return int(left2 * cfg.step * rate), int(right2 * cfg.step * rate)
+    d_amp, d_zcr, T = _run.vad_features(sig, L, S)
+    d_voiced = _run.acr_gate(sig, L, S, rate)
+    left, right = _run.endpoint_rule(d_amp, d_zcr, T, L, cfg.frame, cfg.step, d_voiced)
+    return int(left * cfg.step * rate), int(right * cfg.step * rate)

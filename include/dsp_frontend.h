@@ -188,6 +188,27 @@ int dsp_endpoint_rule_batch(const double* d_amp_sum, const int32_t* d_zcr,
                             double cfg_frame, double cfg_step, int32_t* d_endpoints, void* stream);
 
 /*
+ * endpoint.robust_endpoint_detection (endpoint.py:68-92), batched, in two calls.
+ *
+ * dsp_acr_gate_batch: the autocorrelation gate acr_rule of endpoint.amplitude_rule (endpoint.py:142-144) for EVERY frame
+ * of the rectangular to_frames framing (sigproc.py:11-19): d_voiced[g] = 1 when
+ *     max_{n in [lag_lo, lag_hi)} sigproc.acr(frame, n) / sigproc.acr(frame, 0) > thresh        (sigproc.py:48-53)
+ * -- the caller passes lag_lo = rate // 500, lag_hi = rate // 50, thresh = 0.55 -- accumulated in fp64 (exact for
+ * int16 PCM).  Same batch conventions as dsp_vad_features_batch; lags must not exceed frame_len.
+ *
+ * dsp_endpoint_rule_acr_batch: dsp_endpoint_rule_batch's state machine in the robust form -- amplitude_rule with
+ * mh = 0.5 and use_acr=True (a segment only grows over frames whose d_voiced bit is set, endpoint.py:168-170), one
+ * pass (no mh = 0.125 retry), then zcr_rule and the < 50-frame fallback (endpoint.py:73-90).
+ */
+int dsp_acr_gate_batch(const void* d_wave, int wave_dtype, const int64_t* d_sample_offsets,
+                       const int64_t* d_frame_offsets, int32_t n_utt, int64_t n_frames_total, int64_t uniform_samples,
+                       int32_t frame_len, int32_t frame_step, int32_t lag_lo, int32_t lag_hi, double thresh,
+                       uint8_t* d_voiced, void* stream);
+int dsp_endpoint_rule_acr_batch(const double* d_amp_sum, const int32_t* d_zcr, const uint8_t* d_voiced,
+                                const int64_t* d_frame_offsets, int32_t n_utt, int32_t frame_len, double cfg_frame,
+                                double cfg_step, int32_t* d_endpoints, void* stream);
+
+/*
  * Batch-layout handle: the index tables a ragged call would otherwise build with a small launch of its own (into a
  * pooled workspace) on EVERY call, built ONCE for a batch shape -- the frame offsets of `frame_len` / `frame_step`
  * framing of n_utt utterances.  dsp_vad_features_layout_batch is dsp_vad_features_batch with those tables: no table

@@ -104,6 +104,56 @@ def test_random_clips_endpoints_exact(dtype):
     assert not bad, bad[:5]
 
 
+@pytest.mark.parametrize('dtype,rate', [(np.int16, 16000), (np.float64, 16000), (np.int16, 44100)])
+def test_random_clips_robust_endpoints_exact(dtype, rate):
+    """Random clips with voiced (harmonic) and unvoiced (noise) bursts through the batched device form of
+    endpoint.robust_endpoint_detection (endpoint.py:68-92: dsp_acr_gate_batch + dsp_endpoint_rule_acr_batch): every
+    (left, right) pair must equal the oracle's, and so must the gate bit of every frame."""
+    from features.batch import EndpointPlan
+    from features import _native as nat
+    from oracle import dsp_oracle
+    rng = np.random.default_rng(99 + rate)
+    clips = []
+    for _ in range(200 if rate == 16000 else 60):
+        n = int(rng.uniform(0.3, 2.5) * rate)
+        x = rng.normal(0, rng.choice([1.0, 30.0, 300.0]), n)
+        for _ in range(int(rng.integers(0, 4))):
+            blen = int(rng.uniform(0.05, 0.9) * n)
+            b0 = int(rng.integers(0, max(1, n - blen)))
+            t = np.arange(blen) / float(rate)
+            if rng.random() < 0.7:      # voiced: a few harmonics of a pitch in the gate's range, some of it borderline noisy
+                f0 = rng.uniform(60, 450)
+                burst = sum(np.sin(2 * np.pi * f0 * h * t + rng.uniform(0, 6.28)) / h for h in range(1, int(rng.integers(2, 6))))
+                burst = burst + rng.choice([0.0, 0.3, 1.0, 2.0]) * rng.standard_normal(blen)
+            else:
+                burst = rng.standard_normal(blen)
+            x[b0:b0 + blen] += rng.choice([200.0, 2000.0, 8000.0]) * burst * np.hanning(blen)
+        x = np.clip(np.round(x), -32768, 32767)
+        clips.append(x.astype(np.int16) if dtype == np.int16 else x / 32768.0)
+    so = np.concatenate([[0], np.cumsum([len(c) for c in clips])]).astype(np.int64)
+    flat = np.concatenate(clips)
+    plan = EndpointPlan(rate, 0.03, 0.01, robust=True)
+    got = plan.detect_batch(flat.astype(np.float32) if dtype != np.int16 else flat, sample_offsets=so)
+    voiced = nat.SCRATCH.get('ep_voiced', 1).download((int(plan.layout(flat, so).total_frames),), np.uint8)
+    fo = plan.layout(flat, so).frame_offsets
+    bad, n_voiced, n_gate_bad = [], 0, 0
+    for b, c in enumerate(clips):
+        ref_in = c if dtype == np.int16 else c.astype(np.float32)     # the device sees fp32 samples
+        want = dsp_oracle.robust_endpoint_detection(ref_in, rate)
+        if tuple(got[b]) != want:
+            bad.append((b, tuple(got[b]), want))
+        if b % 10 == 0:     # the gate itself, frame by frame (sigproc.acr in fp64)
+            frames = dsp_oracle.to_frames(ref_in, rate, 0.03, 0.01)
+            for t_, fr in enumerate(frames):
+                e0 = dsp_oracle.acr(fr, 0)
+                with np.errstate(invalid='ignore', divide='ignore'):
+                    w = max(dsp_oracle.acr(fr, n_) for n_ in range(rate // 500, rate // 50)) / e0 > 0.55
+                n_voiced += int(w)
+                n_gate_bad += int(bool(voiced[fo[b] + t_]) != bool(w))
+    assert not bad, bad[:5]
+    assert n_gate_bad == 0 and n_voiced > 50, (n_gate_bad, n_voiced)
+
+
 @pytest.mark.parametrize('nfft,rate,winlen', [(512, 16000, 0.025), (1536, 48000, 0.03)])
 def test_degenerate_signals_through_the_fused_kernels(nfft, rate, winlen):
     """All-zero clips (every filterbank energy and the frame energy hit the eps substitution of
