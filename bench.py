@@ -530,14 +530,20 @@ def main():
     #     gathered to rank 0 over RCCL (features/distributed.py: grouped send/recv, other ranks receive nothing).
     #     Timed on its own, never part of `value`. ---
     gather = None
-    if world > 1 and not args.no_gather and not REHEARSE:
+    gather_failed = False
+    if world > 1 and not args.no_gather:
         from features.distributed import gather_features
-        share_out, share = share_launch(dev, plan, reps=10)
+        share_out, share = share_launch(dev, plan, reps=3 if REHEARSE else 10)
         share_ms = max_over_ranks(share['ms_per_launch'])
         nbytes = SHARE_UTT * T * D * 4
         gather = {'share_launch_ms': share_ms, 'share_frames_per_s_all_ranks': world * SHARE_UTT * T / share_ms * 1e3,
                   'bytes_per_rank': nbytes}
-        try:      # the collective never ran on more than one GPU before the driver's run: its failure must not cost the line
+        if REHEARSE:     # the rehearsal's collectives run over gloo: the same gather code on host copies of the rows
+            share_out = share_out.cpu()
+            gather['rehearsal_note'] = 'gloo on CPU tensors (ranks share cuda:0): the code path, not the RCCL timing'
+        try:      # a failure of the collective is reported in the line AND in the exit code, after the line is out
+            if REHEARSE and os.environ.get('BENCH_FAIL_GATHER') == '1':
+                raise RuntimeError('BENCH_FAIL_GATHER=1 (test of the failure path)')
             rows, _ = gather_features(share_out, dst=0)          # warm-up (communicator set-up, allocations)
             del rows
             sync_all()
@@ -545,13 +551,23 @@ def main():
             rows, counts = gather_features(share_out, dst=0)
             sync_all()
             gms = max_over_ranks((time.perf_counter() - g0) * 1e3)
-            gather.update({'collective': 'rccl gather to rank 0 (grouped send/recv, features/distributed.py::gather_features(dst=0))',
+            gather.update({'collective': ('gloo' if REHEARSE else 'rccl') + ' gather to rank 0 (grouped send/recv, features/distributed.py::gather_features(dst=0))',
                            'ms': gms, 'root_ingest_GBps': (world - 1) * nbytes / gms / 1e6,
                            'rows_at_root': None if rows is None else int(rows.shape[0])})
+            if rank == 0 and (rows is None or int(rows.shape[0]) != world * SHARE_UTT * T):
+                raise RuntimeError(f'gather returned {None if rows is None else int(rows.shape[0])} rows at the root, expected {world * SHARE_UTT * T}')
             del rows
         except Exception as exc:                                 # noqa: BLE001 -- reported in the line
             gather['error'] = repr(exc)[:300]
+            gather_failed = True
         del share_out
+        if world > 1:    # every rank learns of a failure anywhere (the exit code must not depend on the rank)
+            flag = torch.tensor([1.0 if gather_failed else 0.0], dtype=torch.float64, device=cdev)
+            try:
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                gather_failed = bool(flag.item() > 0)
+            except Exception:                                    # noqa: BLE001
+                gather_failed = True
     per_rank_ms = None
     if world > 1:
         mine = torch.tensor([float(np.median([b[1] for b in blocks])) / args.steps], dtype=torch.float64, device=cdev)
@@ -622,14 +638,21 @@ def main():
         res['per_rank_ms_per_step'] = per_rank_ms
     if gather is not None:
         res['gather'] = gather
+        res['gather_failed'] = bool(gather_failed)
     if rank == 0 and world == 1 and not args.no_extras:
         res['other_paths'] = other_paths(dev)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:      # rank 0's host cores, at every N (the other ranks wait at the final barrier)
         res['cpu_baseline'] = cpu_baseline()
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
+        try:
+            dist.barrier()
+        except Exception:                                        # noqa: BLE001
+            pass
         dist.destroy_process_group()
+    if gather_failed:
+        raise SystemExit(3)       # the line is out; the failed collective still fails the run
 
 
 if __name__ == '__main__':

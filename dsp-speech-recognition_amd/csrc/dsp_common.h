@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "dsp_frontend.h"
 
@@ -26,7 +28,31 @@ struct dsp_plan {
     void* d_mfma;           // tables of the matrix-pipe NFFT=512 kernel, kernels_mfma512.h (NULL if not applicable)
     void* d_mfmat;          // tables of its frame-per-product form, kernels_mfma512t.h (NULL if not applicable)
     int device;
+    int dry_run;            // tables live in HOST memory (dsp_debug_host_dry_run): the plan can be destroyed, nothing else
 };
+
+// Table memory of a plan.  Normally device memory; under dsp_debug_host_dry_run(1) (the sanitizer build's CPU tests:
+// `make asan`, tests/test_host_asan.py) plain host memory, so that every host-side table builder runs -- and is checked
+// by ASan / UBSan -- on a machine without a GPU.  Plans made that way carry `dry_run` and refuse every launch.
+extern thread_local int g_host_dry_run;
+static inline hipError_t dsp_table_alloc_copy(void** d, const void* h, size_t bytes) {
+    *d = nullptr;
+    if (g_host_dry_run) {
+        *d = malloc(bytes ? bytes : 1);
+        if (!*d) return hipErrorOutOfMemory;
+        memcpy(*d, h, bytes);
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(d, bytes);
+    if (e != hipSuccess) return e;
+    e = hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(*d); *d = nullptr; }
+    return e;
+}
+static inline void dsp_table_free(void* d, int dry_run) {
+    if (!d) return;
+    if (dry_run) free(d); else (void)hipFree(d);
+}
 
 // Batch geometry handed to every kernel by value.
 struct BatchGeom {

@@ -18,6 +18,8 @@
 #include "kernels_vad.h"
 #include "kernels_pitch.h"
 
+thread_local int g_host_dry_run = 0;   // dsp_debug_host_dry_run: plan tables in host memory (sanitizer build, no GPU)
+
 namespace {
 
 thread_local std::string g_err;
@@ -43,8 +45,7 @@ template <typename T>
 int upload(T** d, const T* h, size_t n) {
     *d = nullptr;
     if (n == 0) return DSP_OK;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(d), n * sizeof(T)));
-    HIP_TRY(hipMemcpy(*d, h, n * sizeof(T), hipMemcpyHostToDevice));
+    HIP_TRY(dsp_table_alloc_copy(reinterpret_cast<void**>(d), h, n * sizeof(T)));
     return DSP_OK;
 }
 
@@ -155,6 +156,11 @@ int dsp_abi_version(void) { return DSP_ABI_VERSION; }
 
 int dsp_debug_force_generic(int on) {
     g_force_generic = on ? 1 : 0;
+    return DSP_OK;
+}
+
+int dsp_debug_host_dry_run(int on) {
+    g_host_dry_run = on ? 1 : 0;
     return DSP_OK;
 }
 
@@ -324,9 +330,11 @@ int dsp_plan_create(const dsp_plan_desc* d, dsp_plan** out) {
         }
     }
     int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
+    if (!g_host_dry_run) HIP_TRY(hipGetDevice(&dev));
     dsp_plan* p = new dsp_plan();
     memset(p, 0, sizeof(*p));
+    p->dry_run = g_host_dry_run ? 1 : 0;
+    if (p->dry_run) dev = -1;      // no device owns these tables: every launch path that checks the plan's device refuses
     p->L = d->frame_len; p->S = d->frame_step; p->nfft = d->nfft; p->K = K;
     p->M = d->nfilt; p->C = d->numcep; p->append_energy = d->append_energy ? 1 : 0;
     p->lfft = d->frame_len < d->nfft ? d->frame_len : d->nfft;
@@ -358,7 +366,7 @@ int dsp_plan_create(const dsp_plan_desc* d, dsp_plan** out) {
 int dsp_plan_destroy(dsp_plan* p) {
     if (!p) return DSP_OK;
     void* bufs[] = {p->d_window, p->d_twiddle, p->d_mel_start, p->d_mel_count, p->d_mel_off, p->d_mel_w, p->d_dct};
-    for (void* b : bufs) (void)hipFree(b);
+    for (void* b : bufs) dsp_table_free(b, p->dry_run);
     fast512_plan_free(p);
     fast1536_plan_free(p);
     mfma512_plan_free(p);
@@ -674,7 +682,7 @@ int dsp_layout_create(const int64_t* d_frame_offsets, int32_t n_utt, int64_t n_f
     dsp_layout* l = new dsp_layout();
     memset(l, 0, sizeof(*l));
     l->n_utt = n_utt; l->frame_len = frame_len; l->frame_step = frame_step; l->n_frames_total = n_frames_total;
-    HIP_TRY(hipGetDevice(&l->device));
+    if (hipGetDevice(&l->device) != hipSuccess) { delete l; return fail(DSP_EHIP, "dsp_layout_create: hipGetDevice failed"); }
     if (tile != 0) {
         l->shift = tile == 16 ? 4 : 2;
         const int64_t bound = n_frames_total / tile + n_utt;
@@ -884,6 +892,8 @@ int dsp_endpoint_layout_segments_batch(const int32_t* d_endpoints, const int64_t
         return fail(DSP_EINVAL, "dsp_endpoint_layout_segments_batch: bad arguments");
     if (!(cfg_step > 0.0) || !(rate > 0.0) || n_frames_bound <= 0)
         return fail(DSP_EINVAL, "dsp_endpoint_layout_segments_batch: step, rate, n_frames_bound must be > 0");
+    if ((n_frames_bound >> 3) + n_utt > 0x3fffffff)   // the kernel's group and tile counters are int32 (as dsp_mfcc_delta_segments_batch checks)
+        return fail(DSP_EINVAL, "dsp_endpoint_layout_segments_batch: batch too large");
     const SegWork w = seg_work_layout(n_utt, n_frames_bound, plan->C);
     if (work_bytes < w.total) return fail(DSP_EINVAL, "work buffer too small (%zu < %zu bytes)", work_bytes, w.total);
     char* wp = static_cast<char*>(d_work);

@@ -669,9 +669,7 @@ static inline int fast1536_plan_init(dsp_plan* p, const dsp_plan_desc* d, const 
     memcpy(blob.data() + o_melw, melw.data(), melw.size() * 4);
     memcpy(blob.data() + o_mels, mels.data(), mels.size() * 4);
     memcpy(blob.data() + o_pidx, pidx.data(), pidx.size() * 4);
-    if (hipMalloc(reinterpret_cast<void**>(&fp->d_tables), total * 4) != hipSuccess ||
-        hipMemcpy(fp->d_tables, blob.data(), total * 4, hipMemcpyHostToDevice) != hipSuccess) {
-        if (fp->d_tables) (void)hipFree(fp->d_tables);
+    if (dsp_table_alloc_copy(reinterpret_cast<void**>(&fp->d_tables), blob.data(), total * 4) != hipSuccess) {
         delete fp;
         return DSP_EHIP;
     }
@@ -693,7 +691,7 @@ static inline int fast1536_plan_init(dsp_plan* p, const dsp_plan_desc* d, const 
 static inline void fast1536_plan_free(dsp_plan* p) {
     Fast1536Plan* fp = static_cast<Fast1536Plan*>(p->d_fast1536);
     if (!fp) return;
-    (void)hipFree(fp->d_tables);
+    dsp_table_free(fp->d_tables, p->dry_run);
     delete fp;
     p->d_fast1536 = nullptr;
 }

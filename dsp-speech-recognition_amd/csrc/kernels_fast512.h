@@ -1429,8 +1429,7 @@ static inline int fast512_plan_init(dsp_plan* p, const dsp_plan_desc* d, const i
     memcpy(blob.data() + o_mels, mels.data(), mels.size() * 4);
     memcpy(blob.data() + o_bias, bias.data(), bias.size() * 4);
     memcpy(blob.data() + o_coop, coop.data(), coop.size() * 4);
-    if (hipMalloc(reinterpret_cast<void**>(&fp->d_tables), total * 4) != hipSuccess ||
-        hipMemcpy(fp->d_tables, blob.data(), total * 4, hipMemcpyHostToDevice) != hipSuccess) {
+    if (dsp_table_alloc_copy(reinterpret_cast<void**>(&fp->d_tables), blob.data(), total * 4) != hipSuccess) {
         delete fp;
         return DSP_EHIP;
     }
@@ -1453,7 +1452,7 @@ static inline int fast512_plan_init(dsp_plan* p, const dsp_plan_desc* d, const i
 static inline void fast512_plan_free(dsp_plan* p) {
     Fast512Plan* fp = static_cast<Fast512Plan*>(p->d_fast);
     if (!fp) return;
-    (void)hipFree(fp->d_tables);
+    dsp_table_free(fp->d_tables, p->dry_run);
     delete fp;
     p->d_fast = nullptr;
 }

@@ -390,6 +390,17 @@ __global__ __launch_bounds__(256) void delta_rows_kernel(const float* __restrict
             if (i0 + 256 * k < rows_x * D) sx[i0 + 256 * k] = v[k];
     }
     __syncthreads();
+    if (stats != nullptr) {
+        // the shift of c0 goes into the window BEFORE the deltas: a frame of exactly zero energy keeps ln(eps) while its
+        // neighbours move, so delta and delta-delta of c0 around digital silence see the shifted values, as when the
+        // clip is scaled first (model.py:62-63, then base.py:26 and :70-79)
+        const float shift = s_shift;
+        for (int r = threadIdx.x; r < rows_x; r += 256) {
+            const float x0 = sx[r * D];
+            if (x0 != -36.04365338911715f) sx[r * D] = x0 - shift;
+        }
+        __syncthreads();
+    }
     for (int i = threadIdx.x; i < rows_d * D; i += 256) {
         const int r = i / D, d = i - r * D;
         int tt = t0 - N + r;
@@ -407,9 +418,7 @@ __global__ __launch_bounds__(256) void delta_rows_kernel(const float* __restrict
         float acc = 0.f;
         for (int n = 1; n <= N; ++n) acc = fmaf((float)n, sd[(r + N + n) * D + d] - sd[(r + N - n) * D + d], acc);
         float* o = out_u + r * 3 * D + d;
-        float x0 = sx[(r + 2 * N) * D + d];
-        if (d == 0 && x0 != -36.04365338911715f) x0 -= s_shift;
-        o[0] = x0;
+        o[0] = sx[(r + 2 * N) * D + d];
         o[D] = sd[(r + N) * D + d];
         o[2 * D] = acc * inv_den;
     }

@@ -796,12 +796,7 @@ static inline int mfma512_plan_init(dsp_plan* p, const dsp_plan_desc* d) {
     if (rc != 0) return DSP_OK;                               // not served: the other kernels take the plan
     Mfma512Plan* mp = new Mfma512Plan();
     mp->lay = lay;
-    if (hipMalloc(&mp->d_tables, blob.size()) != hipSuccess) { delete mp; return DSP_EHIP; }
-    if (hipMemcpy(mp->d_tables, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess) {
-        (void)hipFree(mp->d_tables);
-        delete mp;
-        return DSP_EHIP;
-    }
+    if (dsp_table_alloc_copy(reinterpret_cast<void**>(&mp->d_tables), blob.data(), blob.size()) != hipSuccess) { delete mp; return DSP_EHIP; }
     p->d_mfma = mp;
     return DSP_OK;
 }
@@ -809,7 +804,7 @@ static inline int mfma512_plan_init(dsp_plan* p, const dsp_plan_desc* d) {
 static inline void mfma512_plan_free(dsp_plan* p) {
     if (!p->d_mfma) return;
     Mfma512Plan* mp = static_cast<Mfma512Plan*>(p->d_mfma);
-    (void)hipFree(mp->d_tables);
+    dsp_table_free(mp->d_tables, p->dry_run);
     delete mp;
     p->d_mfma = nullptr;
 }

@@ -80,17 +80,20 @@ class DspWorkspacePool {
         while (want < bytes) want *= 2;
         const size_t cap = cap_bytes();
         const bool may_grow = total_ + want <= cap;
-        // 1. best fit among the buffers last used on this stream (no event query: stream order is enough)
+        // 1. best fit among the buffers last used on this stream: stream order is enough -- for an ordinary stream
+        //    handle.  hipStreamPerThread is one handle value naming a different stream in every thread, so it never
+        //    takes this shortcut (step 2 asks the buffer's event instead).
+        const bool same_stream_ok = st != hipStreamPerThread;
         DspWorkspace* best = nullptr;
         for (DspWorkspace* w : all_)
-            if (!w->leased && w->device == dev && w->bytes >= bytes && (!w->used || w->last_stream == st) &&
+            if (!w->leased && w->device == dev && w->bytes >= bytes && (!w->used || (same_stream_ok && w->last_stream == st)) &&
                 (!best || w->bytes < best->bytes)) best = w;
         if (best && (best->bytes <= 8 * want || !may_grow)) return lease(best);
         // 2. best fit among the buffers of other streams whose last user has finished
         best = nullptr;
         for (DspWorkspace* w : all_) {
             if (w->leased || w->device != dev || w->bytes < bytes || (best && w->bytes >= best->bytes)) continue;
-            if (w->used && w->last_stream != st) {
+            if (w->used && (w->last_stream != st || !same_stream_ok)) {
                 const hipError_t qe = hipEventQuery(w->done);
                 if (qe != hipSuccess) {  // still in flight (or error)
                     if (dbg) fprintf(stderr, "[ws]   query %zu B: %s\n", w->bytes, hipGetErrorName(qe));
@@ -121,7 +124,7 @@ class DspWorkspacePool {
         for (DspWorkspace* w : all_)
             if (!w->leased && w->device == dev && w->bytes >= bytes && (!best || w->bytes < best->bytes)) best = w;
         if (!best) return nullptr;
-        if (best->used && best->last_stream != st && hipEventSynchronize(best->done) != hipSuccess) {
+        if (best->used && (best->last_stream != st || !same_stream_ok) && hipEventSynchronize(best->done) != hipSuccess) {
             (void)hipGetLastError();
             return nullptr;
         }

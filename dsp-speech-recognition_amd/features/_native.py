@@ -52,6 +52,7 @@ SIGNATURES = {
     'dsp_debug_force_generic': (C.c_int, [C.c_int]),
     'dsp_debug_pool_stats': (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     'dsp_debug_use_mfma512': (C.c_int, [C.c_int]),
+    'dsp_debug_host_dry_run': (C.c_int, [C.c_int]),
     'dsp_plan_has_mfma512': (C.c_int, [c_vp]),
     'dsp_preemphasis_batch': (C.c_int, [c_vp, C.c_int, c_vp, c_i32, c_i64, c_f32, c_vp, c_vp]),
     'dsp_features_batch': (C.c_int, [c_vp, c_vp, C.c_int, c_vp, c_vp, c_i32, c_i64, c_i64, C.c_int,

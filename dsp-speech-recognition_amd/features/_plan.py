@@ -102,8 +102,11 @@ def lifter_vector(ncoeff, L=22):
 class Plan:
     """Owns one dsp_plan handle plus the host copies of its tables."""
 
-    def __init__(self, L, S, nfft, window, preemph=0.0, fb=None, dct=None, append_energy=False):
-        nat.require_device()
+    def __init__(self, L, S, nfft, window, preemph=0.0, fb=None, dct=None, append_energy=False, host_dry_run=False):
+        # host_dry_run (tests of the sanitizer build only): every host-side table builder runs, the tables stay in host
+        # memory, no device is touched; the plan can be destroyed and nothing else (include/dsp_frontend.h)
+        if not host_dry_run:
+            nat.require_device()
         self.L, self.S, self.nfft = int(L), int(S), int(nfft)
         self.K = self.nfft // 2 + 1
         self.window = np.ascontiguousarray(window, dtype=np.float32)
@@ -130,7 +133,13 @@ class Plan:
             self._keep.append(d32)
             desc.h_dct = d32.ctypes.data
         h = C.c_void_p(0)
-        nat.check(nat.load().dsp_plan_create(C.byref(desc), C.byref(h)))
+        if host_dry_run:
+            nat.check(nat.load().dsp_debug_host_dry_run(1))
+        try:
+            nat.check(nat.load().dsp_plan_create(C.byref(desc), C.byref(h)))
+        finally:
+            if host_dry_run:
+                nat.check(nat.load().dsp_debug_host_dry_run(0))
         self.handle = h.value
 
     def __del__(self):

@@ -77,14 +77,15 @@ class _BatchLayout:
         instead of on every call (include/dsp_frontend.h: dsp_layout_create).  None for dense or scratch layouts."""
         if self.uniform_samples > 0 or not isinstance(self.d_frame, nat.DeviceBuffer):
             return None
-        h = getattr(self, '_vad_handle', None)
+        handles = self.__dict__.setdefault('_vad_handles', {})    # one per framing: the tables depend on (L, S)
+        h = handles.get((int(L), int(S)))
         if h is None:
             import ctypes as C
             out = C.c_void_p(0)
             nat.check(nat.load().dsp_layout_create(self.d_frame.ptr, self.n_utt, self.total_frames, int(L), int(S), None,
                                                    C.byref(out)))
             nat.check(nat.load().dsp_stream_synchronize(None))
-            h = self._vad_handle = _LayoutHandle(out.value)
+            h = handles[(int(L), int(S))] = _LayoutHandle(out.value)
         return h.handle
 
 

@@ -116,6 +116,11 @@ int dsp_debug_use_mfma512(int on);
 int dsp_plan_has_mfma512(const dsp_plan* plan);
 /* testing aid: device workspaces (index tables, cepstra scratch) the library's pool currently holds */
 int dsp_debug_pool_stats(long long* n_buffers, long long* bytes);
+/* on = 1: dsp_plan_create on the calling thread runs every host-side table builder (window / twiddle / mel / DCT tables,
+   the fused kernels' and the matrix-pipe kernels' operand tables) but keeps the tables in HOST memory and never touches a
+   device -- for the sanitizer build (`make -C dsp-speech-recognition_amd/csrc asan`, tests/test_host_asan.py), which runs
+   on a machine without a GPU.  Such a plan can only be destroyed; launches with it are refused. */
+int dsp_debug_host_dry_run(int on);
 
 /* ---- the hot path -------------------------------------------------------------------------- */
 /*

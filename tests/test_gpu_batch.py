@@ -317,6 +317,10 @@ def test_config4_vad_trim_mfcc_pipeline(unit_variance, copy_trimmed):
     clips.append(make_signal(('int16', 77, 9000)))      # no burst: whole-clip fallback
     clips.append(make_signal(('bursts', 78, 32000)))
     clips.append((make_signal(('vad', 300, 20000)).astype(np.int32) + 6000).clip(-32768, 32767).astype(np.int16))  # DC offset >> noise floor
+    hole = make_signal(('vad', 301, 24000)).copy()     # 700 samples of digital silence INSIDE the detected segment: frames
+    mid = int(np.argmax(np.abs(hole.astype(np.int32))))   # of zero energy keep ln(eps) while their neighbours' c0 shifts
+    hole[mid - 350:mid + 350] = 0                      # by ln(var) -- the deltas of c0 around them must see that
+    clips.append(hole)
     so = np.concatenate([[0], np.cumsum([len(c) for c in clips])]).astype(np.int64)
     pipe = VadMfccPipeline(rate=16000, unit_variance=unit_variance, winfunc=np.hamming,
                            **{k: v for k, v in CFG.items() if k != 'samplerate'})

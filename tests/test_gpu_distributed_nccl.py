@@ -123,10 +123,31 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     env.pop('WORLD_SIZE', None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '10', '--warmup', '2',
                         '--min-time', '0.05', '--buffers', '2', '--no-cpu-baseline', '--no-extras'],
-                       capture_output=True, text=True, timeout=600, env=env)
+                       capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, r.stdout
     j = json.loads(lines[0])
     assert j['n_gpus'] == 2 and j['rehearsal'] is True and len(j['per_rank_ms_per_step']) == 2
     assert j['value'] > 0 and j['scaling'] == 'weak' and j['parity_normwise_vs_oracle'] <= 1e-4
+    # configs[2]: every rank's 12 500-utterance share computed in one launch, then the gather code path of
+    # features/distributed.py (here over gloo on host copies): all rows arrive at the root, no failure flag
+    assert j['gather_failed'] is False and 'error' not in j['gather']
+    assert j['gather']['rows_at_root'] == 2 * 12500 * 99 and j['gather']['bytes_per_rank'] == 12500 * 99 * 39 * 4
+
+
+@pytest.mark.gpu
+def test_bench_gather_failure_sets_the_flag_and_the_exit_code():
+    """A failing collective must not cost the JSON line, but it must show: top-level "gather_failed": true and a
+    non-zero exit code (BENCH_FAIL_GATHER=1 makes features.distributed.gather_features raise in the rehearsal)."""
+    import json
+    env = dict(os.environ, BENCH_REHEARSE_GLOO='1', BENCH_FAIL_GATHER='1')
+    env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '1',
+                        '--min-time', '0.05', '--buffers', '2', '--no-cpu-baseline', '--no-extras'],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode != 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j['gather_failed'] is True and 'error' in j['gather'] and j['value'] > 0

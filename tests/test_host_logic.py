@@ -32,6 +32,20 @@ def test_header_symbols_exported(nat):
     assert lib.dsp_abi_version() == 1
 
 
+def test_library_exports_nothing_the_header_does_not_declare(nat):
+    """The other direction: every `dsp_*` function the shipped library exports is declared in include/dsp_frontend.h
+    (the per-phase stamp readers exist only in diagnostic builds compiled with -DF512_STAMPS / -DM512_STAMPS /
+    -DM512T_STAMPS; the product build must not carry them)."""
+    import shutil
+    import subprocess
+    nm = shutil.which('nm') or '/opt/rocm/lib/llvm/bin/llvm-nm'
+    out = subprocess.run([nm, '-D', '--defined-only', nat.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith('dsp_') and ' T ' in ln}
+    hdr = open(os.path.join(ROOT, 'include', 'dsp_frontend.h')).read()
+    declared = set(re.findall(r'\b(dsp_[a-z0-9_]+)\s*\(', hdr))
+    assert exported and exported <= declared, sorted(exported - declared)
+
+
 def test_plan_desc_layout_matches_header(nat):
     import ctypes as C
     # 6 int32 + 1 float (28 bytes, padded to 32) + 5 pointers
