@@ -1034,4 +1034,49 @@ int dsp_endpoint_rule_acr_batch(const double* d_amp_sum, const int32_t* d_zcr, c
     return DSP_OK;
 }
 
+int dsp_resample_layout_batch(const int64_t* d_src_offsets, int32_t n_utt, int64_t src_rate, int64_t dst_rate,
+                              int32_t frame_len, int32_t frame_step, int64_t* d_dst_offsets, int64_t* d_frame_offsets,
+                              void* stream) {
+    if (!d_src_offsets || !d_frame_offsets || n_utt <= 0 || frame_len <= 0 || frame_step <= 0)
+        return fail(DSP_EINVAL, "dsp_resample_layout_batch: bad arguments");
+    if (dst_rate < 0 || (dst_rate > 0 && (src_rate <= 0 || dst_rate >= src_rate || !d_dst_offsets)))
+        return fail(DSP_EINVAL, "dsp_resample_layout_batch: need 0 < dst_rate < src_rate and d_dst_offsets (a decimation), or dst_rate = 0");
+    resample_layout_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(d_src_offsets, n_utt, src_rate, dst_rate, frame_len, frame_step,
+                                                               d_dst_offsets, d_frame_offsets);
+    HIP_TRY(hipGetLastError());
+    return DSP_OK;
+}
+
+int dsp_decimate_batch(const float* d_in, const int64_t* d_src_offsets, const int64_t* d_dst_offsets, int32_t n_utt,
+                       int64_t n_out_bound, int64_t src_rate, int64_t dst_rate, float* d_out, void* stream) {
+    if (!d_in || !d_src_offsets || !d_dst_offsets || !d_out || n_utt <= 0)
+        return fail(DSP_EINVAL, "dsp_decimate_batch: bad arguments");
+    if (src_rate <= 0 || dst_rate <= 0 || dst_rate >= src_rate) return fail(DSP_EINVAL, "dsp_decimate_batch: need 0 < dst_rate < src_rate");
+    if (n_out_bound <= 0) return DSP_OK;
+    decimate_gather_kernel<<<grid_for(n_out_bound, 256), 256, 0, (hipStream_t)stream>>>(d_in, d_src_offsets, d_dst_offsets, n_utt,
+                                                                                         src_rate, dst_rate, d_out);
+    HIP_TRY(hipGetLastError());
+    return DSP_OK;
+}
+
+int dsp_model_pitchfeat_batch(const double* d_pitch, const int64_t* d_frame_offsets, int32_t n_utt, int32_t max_len,
+                              float* d_out, void* stream) {
+    if (!d_pitch || !d_frame_offsets || !d_out || n_utt <= 0 || max_len <= 0)
+        return fail(DSP_EINVAL, "dsp_model_pitchfeat_batch: bad arguments");
+    pitchfeat_finalize_kernel<<<n_utt, 64, 0, (hipStream_t)stream>>>(d_pitch, d_frame_offsets, n_utt, max_len, d_out);
+    HIP_TRY(hipGetLastError());
+    return DSP_OK;
+}
+
+int dsp_pitch_rows_batch(double* d_rows, const int64_t* d_frame_offsets, int32_t n_utt, int32_t n_lags, int32_t bias,
+                         int32_t degree, int32_t flags, double* d_pitch, void* stream) {
+    if (!d_rows || !d_frame_offsets || n_utt <= 0 || n_lags <= 0 || degree < 0)
+        return fail(DSP_EINVAL, "dsp_pitch_rows_batch: bad arguments");
+    if ((flags & 4) && !(flags & 2)) return fail(DSP_EINVAL, "dsp_pitch_rows_batch: the repair sweeps (4) need the arg-max (2)");
+    if ((flags & 2) && !d_pitch) return fail(DSP_EINVAL, "dsp_pitch_rows_batch: d_pitch is NULL");
+    pitch_rows_kernel<<<n_utt, 64, 0, (hipStream_t)stream>>>(d_rows, d_frame_offsets, n_lags, bias, degree, flags, d_pitch);
+    HIP_TRY(hipGetLastError());
+    return DSP_OK;
+}
+
 }  // extern "C"

@@ -28,6 +28,7 @@ __global__ __launch_bounds__(PITCH_THREADS) void pitch_scores_kernel(
     const int64_t g = blockIdx.x;
     int32_t utt;
     int64_t t, s0, nsamp;
+    if (bg.uniform_frames <= 0 && g >= bg.frame_off[bg.n_utt]) return;   // the grid may be sized by an upper bound of the frame count
     dsp_locate(bg, g, utt, t, s0, nsamp);
     const int64_t first = t * (int64_t)S;
     if (tid == 0) s_m = 0;
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(64) void pitch_scores_kernel_v2(
     const int64_t g = blockIdx.x;
     int32_t utt;
     int64_t t, s0, nsamp;
+    if (bg.uniform_frames <= 0 && g >= bg.frame_off[bg.n_utt]) return;   // the grid may be sized by an upper bound of the frame count
     dsp_locate(bg, g, utt, t, s0, nsamp);
     const int64_t first = t * (int64_t)S;
     float* cl = cl0 + Lp;
@@ -353,4 +355,158 @@ __global__ __launch_bounds__(64) void pitch_track_kernel(const float* __restrict
     }
     __syncthreads();
     for (int i = lane; i < T && i < PITCH_TRACK_LDS_FRAMES; i += 64) out[i] = s_pitch[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Device-side glue of the optional streams of model.py:90-101, so that ModelFeatureBatch never brings the trimmed
+// clips to the host: decimation to 10 kHz (preprocess.downsampling, preprocess.py:21-28), frame offsets of a
+// framing on the device, the [max_len, B, 2] pitch stream, and the tracker's parts for fp64 score rows.
+// ------------------------------------------------------------------------------------------------
+
+// preprocess.py:21-28 keeps sample i whenever  i * dst / src > kept - 1 + 1e-8  (Python: exact integer product, one
+// fp64 division).  For a decimation (dst < src) the k-th kept index is the smallest i that passes the test for tick k.
+__device__ __forceinline__ bool dsp_dec_pass(int64_t i, int64_t k, int64_t src, int64_t dst) {
+    return (double)(i * dst) / (double)src > (double)(k - 1) + 1e-8;
+}
+__device__ __forceinline__ int64_t dsp_dec_index(int64_t k, int64_t src, int64_t dst) {
+    int64_t i = (int64_t)floor(((double)(k - 1) + 1e-8) * (double)src / (double)dst);
+    if (i < 0) i = 0;
+    while (!dsp_dec_pass(i, k, src, dst)) ++i;
+    while (i > 0 && dsp_dec_pass(i - 1, k, src, dst)) --i;
+    return i;
+}
+__device__ __forceinline__ int64_t dsp_dec_count(int64_t n, int64_t src, int64_t dst) {   // samples kept of n
+    if (n <= 0) return 0;
+    int64_t k = (int64_t)floor((double)((n - 1) * dst) / (double)src) + 1;
+    while (dsp_dec_index(k, src, dst) < n) ++k;
+    while (k > 0 && dsp_dec_index(k - 1, src, dst) >= n) --k;
+    return k;
+}
+
+// One 1024-thread block: lengths n_b = src_off[b+1] - src_off[b]  ->  (optional) decimated lengths and their exclusive
+// prefix dst_off, and the exclusive prefix frame_off of the frame counts of the (decimated) lengths at (L, S)
+// (sigproc.py:79-82).  dst_rate == 0: no decimation (frame offsets of another framing of the same clips).
+__global__ __launch_bounds__(1024) void resample_layout_kernel(const int64_t* __restrict__ src_off, int32_t n_utt,
+                                                               int64_t src_rate, int64_t dst_rate, int32_t L, int32_t S,
+                                                               int64_t* __restrict__ dst_off, int64_t* __restrict__ frame_off) {
+    __shared__ int64_t part_s[16], part_f[16];
+    const int tid = threadIdx.x;
+    const int per = (n_utt + 1023) / 1024;
+    const int lo = tid * per, hi = min(lo + per, n_utt);
+    int64_t sum_s = 0, sum_f = 0;
+    for (int b = lo; b < hi; ++b) {
+        int64_t n = src_off[b + 1] - src_off[b];
+        if (dst_rate > 0) n = dsp_dec_count(n, src_rate, dst_rate);
+        sum_s += n;
+        sum_f += n <= L ? 1 : 1 + (n - L + S - 1) / S;
+    }
+    const int64_t in_s = dsp_wave_scan_i64(sum_s), in_f = dsp_wave_scan_i64(sum_f);
+    if ((tid & 63) == 63) { part_s[tid >> 6] = in_s; part_f[tid >> 6] = in_f; }
+    __syncthreads();
+    int64_t base_s = in_s - sum_s, base_f = in_f - sum_f;
+    for (int w = 0; w < (tid >> 6); ++w) { base_s += part_s[w]; base_f += part_f[w]; }
+    for (int b = lo; b < hi; ++b) {
+        int64_t n = src_off[b + 1] - src_off[b];
+        if (dst_rate > 0) n = dsp_dec_count(n, src_rate, dst_rate);
+        if (dst_off) dst_off[b] = base_s;
+        frame_off[b] = base_f;
+        base_s += n;
+        base_f += n <= L ? 1 : 1 + (n - L + S - 1) / S;
+    }
+    if (hi == n_utt && lo < hi) {
+        if (dst_off) dst_off[n_utt] = base_s;
+        frame_off[n_utt] = base_f;
+    }
+    if (n_utt == 0 && tid == 0) { if (dst_off) dst_off[0] = 0; frame_off[0] = 0; }
+}
+
+// out[dst_off[b] + k] = in[src_off[b] + index of the k-th kept sample]  (preprocess.py:21-28), one thread per output
+__global__ __launch_bounds__(256) void decimate_gather_kernel(const float* __restrict__ in, const int64_t* __restrict__ src_off,
+                                                              const int64_t* __restrict__ dst_off, int32_t n_utt,
+                                                              int64_t src_rate, int64_t dst_rate, float* __restrict__ out) {
+    const int64_t total = dst_off[n_utt];
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t u = dsp_find_utt(dst_off, n_utt, o);
+        out[o] = in[src_off[u] + dsp_dec_index(o - dst_off[u], src_rate, dst_rate)];
+    }
+}
+
+// model.py:90-95: out[t, b, 0] = pitch[t] / 150, out[t, b, 1] = their first difference (T - 1 rows), zero padded /
+// truncated to max_len rows (model.py:35-50).  One wave per utterance.
+__global__ __launch_bounds__(64) void pitchfeat_finalize_kernel(const double* __restrict__ pitch,
+                                                                const int64_t* __restrict__ frame_off, int32_t n_utt,
+                                                                int32_t max_len, float* __restrict__ out) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int64_t base = frame_off[b];
+    const int T = (int)(frame_off[b + 1] - base);
+    const double* p = pitch + base;
+    for (int t = lane; t < max_len; t += 64) {
+        float z0 = 0.f, z1 = 0.f;
+        if (t < T) {
+            const double a = p[t] / 150.0;
+            z0 = (float)a;
+            if (t + 1 < T) z1 = (float)(p[t + 1] / 150.0 - a);
+        }
+        float* o = out + ((int64_t)t * n_utt + b) * 2;
+        o[0] = z0;
+        o[1] = z1;
+    }
+}
+
+// The tracker's parts on fp64 score rows (the host helpers pitch.smooth / max_pitch / robust_max_pitch are batches of
+// one through this): flags bit 0 = smooth in place over rows [i - degree, i + degree) (pitch.py:157-164: the rows
+// before i are already smoothed; the window's end is exclusive and stops at T - 1; an empty window is a NaN row),
+// bit 1 = arg-max -> 1 / (1e-4 (bias + idx)) (pitch.py:166-172), bit 2 = the two octave-repair sweeps
+// (pitch.py:191-206).  `rows` is overwritten by the smoothed rows when bit 0 is set.  One wave per utterance.
+__global__ __launch_bounds__(64) void pitch_rows_kernel(double* __restrict__ rows, const int64_t* __restrict__ frame_off,
+                                                        int32_t n_lags, int32_t bias, int32_t degree, int32_t flags,
+                                                        double* __restrict__ pitch) {
+    const int u = blockIdx.x, lane = threadIdx.x;
+    const int64_t base = frame_off[u];
+    const int T = (int)(frame_off[u + 1] - base);
+    if (T <= 0) return;
+    double* g = rows + base * n_lags;
+    double* out = pitch ? pitch + base : nullptr;
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    for (int i = 0; i < T; ++i) {
+        double bv = -__longlong_as_double(0x7ff0000000000000ll);
+        int bi = 0x7fffffff;
+        for (int lag = lane; lag < n_lags; lag += 64) {
+            double cur = g[(int64_t)i * n_lags + lag];
+            if (flags & 1) {
+                const int left = i - degree >= 0 ? i - degree : 0;
+                const int right = i + degree < T ? i + degree : T - 1;      // exclusive
+                double acc = qnan;
+                bool have = false;
+                for (int r = left; r < right; ++r) {                         // rows in order (rows < i: already smoothed, same lane wrote them)
+                    const double v = g[(int64_t)r * n_lags + lag];
+                    acc = have ? acc + v : v;
+                    have = true;
+                }
+                cur = have ? acc / (double)(right - left) : qnan;
+                g[(int64_t)i * n_lags + lag] = cur;
+            }
+            pitch_argmax_combine(bv, bi, cur, lag);
+        }
+        if (flags & 2) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ov = __shfl_xor(bv, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                pitch_argmax_combine(bv, bi, ov, oi);
+            }
+            if (lane == 0) out[i] = 1.0 / (0.0001 * (double)(bias + bi));
+        }
+    }
+    if ((flags & 4) && lane == 0) {
+        const double C = 50.0;
+        for (int i = 1; i < T; ++i) {
+            const double p = out[i];
+            if (fabs(2.0 * p - out[i - 1]) < C && p < 170.0) out[i] = 2.0 * p;
+        }
+        for (int i = T - 2; i > 0; --i) {
+            const double p = out[i];
+            if (fabs(2.0 * p - out[i + 1]) < C && p < 170.0) out[i] = 2.0 * p;
+        }
+    }
 }

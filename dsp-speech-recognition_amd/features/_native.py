@@ -81,6 +81,10 @@ SIGNATURES = {
     'dsp_pitch_scores_batch': (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_vp, c_i32,
                                          c_i32, c_i32, c_vp, c_vp]),
     'dsp_pitch_track_batch': (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    'dsp_pitch_rows_batch': (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    'dsp_resample_layout_batch': (C.c_int, [c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    'dsp_decimate_batch': (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_i64, c_vp, c_vp]),
+    'dsp_model_pitchfeat_batch': (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     'dsp_model_finalize_batch': (C.c_int, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
 }
 

@@ -190,47 +190,44 @@ class ModelFeatureBatch:
 
     def _timefeat_streams(self, lay, st, dev):
         """[max_len, B, 2]: z-scored frame amplitude of the trimmed, scaled clips and its first difference
-        (model.py:97-101), on the device."""
+        (model.py:97-101), on the device -- at the amplitude stream's OWN framing (int(rate * cfg.frame),
+        int(cfg.step * rate): to_frames truncates, sigproc.py:19; the MFCC framing rounds half up, so the two differ at
+        e.g. 22.05 kHz): its frame offsets come from one small launch over the trimmed offsets."""
         import torch
         from . import _native as nat
         lib = nat.load()
         ep, fp = self.pipe.endpoint, self.pipe.features
         L2, S2 = int(self.rate * ep.frame), int(ep.step * self.rate)       # to_frames truncation, sigproc.py:19
-        if (L2, S2) != (fp.L, fp.S):
-            raise NotImplementedError('amplitude framing differs from the MFCC framing at this rate; use '
-                                      'feature_extract_timespace per utterance')
         B = lay.n_utt
-        d_amp = torch.empty(max(lay.frames_bound, 1), dtype=torch.float64, device=dev)
-        d_zcr = torch.empty(max(lay.frames_bound, 1), dtype=torch.int32, device=dev)
-        nat.check(lib.dsp_vad_features_batch(lay.d_trim.ptr, nat.WAVE_F32, lay.d_dst_off.ptr, lay.d_frame_off.ptr, B,
-                                             lay.frames_bound, 0, L2, S2, 0, d_amp.data_ptr(), d_zcr.data_ptr(), st))
+        if (L2, S2) == (fp.L, fp.S):
+            p_fo, frames_bound = lay.d_frame_off.ptr, lay.frames_bound
+        else:
+            d_fo2 = torch.empty(B + 1, dtype=torch.int64, device=dev)
+            nat.check(lib.dsp_resample_layout_batch(lay.d_dst_off.ptr, B, int(self.rate), 0, L2, S2, None, d_fo2.data_ptr(), st))
+            p_fo, frames_bound = d_fo2.data_ptr(), int(lay.total_samples) // S2 + B + 1
+        d_amp = torch.empty(max(frames_bound, 1), dtype=torch.float64, device=dev)
+        d_zcr = torch.empty(max(frames_bound, 1), dtype=torch.int32, device=dev)
+        nat.check(lib.dsp_vad_features_batch(lay.d_trim.ptr, nat.WAVE_F32, lay.d_dst_off.ptr, p_fo, B,
+                                             frames_bound, 0, L2, S2, 0, d_amp.data_ptr(), d_zcr.data_ptr(), st))
         out = torch.empty((self.max_len, B, 2), dtype=torch.float32, device=dev)
-        nat.check(lib.dsp_model_timefeat_batch(d_amp.data_ptr(), lay.d_frame_off.ptr, B, L2, self.max_len,
+        nat.check(lib.dsp_model_timefeat_batch(d_amp.data_ptr(), p_fo, B, L2, self.max_len,
                                                out.data_ptr(), st))
-        nat.check(lib.dsp_stream_synchronize(st))            # d_amp / d_zcr are released on return
+        nat.check(lib.dsp_stream_synchronize(st))            # d_amp / d_zcr / the offsets are released on return
         return out
 
     def _pitch_streams(self, lay, st, dev):
         """[max_len, B, 2]: pitch track / 150 and its first difference (model.py:90-95) of the trimmed, scaled
-        clips.  The tracker's score kernel is batched per clip; smoothing, arg-max and octave repair are the
-        reference's sequential host logic, so this stream downloads the clips and loops over them."""
+        clips, on the device: decimation to 10 kHz (an index selection, preprocess.py:21-28), frame scores, smoothing,
+        arg-max, octave repair (pitch.py:96-206) and the [max_len, B, 2] layout -- six launches, no clip and no track
+        crosses PCIe."""
         import torch
-        from .pitch import downsampling, pitch_tracks_batch
+        from . import _native as nat
+        from .pitch import pitch_tracks_device
+        lib = nat.load()
         B = lay.n_utt
-        dst = lay.d_dst_off.download((B + 1,), np.int64, st)
-        clips = lay.d_trim.download((int(dst[-1]),), np.float32, st)
-        # pitch.pitch_detect_sr for the whole batch: decimation to 10 kHz on the host (an index selection,
-        # preprocess.py:21-28), then scores, smoothing, arg-max and octave repair on the device in two launches
         cfg = _endpoint.cfg
         L, S = int(10000 * cfg.frame), int(cfg.step * 10000)
-        downs = [downsampling(clips[dst[b]:dst[b + 1]], self.rate, 10000) for b in range(B)]
-        so10 = np.concatenate([[0], np.cumsum([len(d) for d in downs])]).astype(np.int64)
-        pitch, fo = pitch_tracks_batch(np.concatenate(downs) if so10[-1] else np.zeros(0, dtype=np.float32), so10, L, S)
-        out = np.zeros((self.max_len, B, 2), dtype=np.float32)
-        for b in range(B):
-            p0 = (pitch[fo[b]:fo[b + 1]] / 150).reshape(-1, 1)          # model.py:93
-            p1 = deviation(p0).reshape(-1, 1)                            # model.py:94
-            n0, n1 = min(len(p0), self.max_len), min(len(p1), self.max_len)
-            out[:n0, b, 0] = p0[:n0, 0]
-            out[:n1, b, 1] = p1[:n1, 0]
-        return torch.from_numpy(out).to(dev)
+        d_pitch, d_fo = pitch_tracks_device(lay.d_trim.ptr, lay.d_dst_off.ptr, B, int(lay.total_samples), self.rate, L, S, st)
+        out = torch.empty((self.max_len, B, 2), dtype=torch.float32, device=dev)
+        nat.check(lib.dsp_model_pitchfeat_batch(d_pitch.ptr, d_fo.ptr, B, self.max_len, out.data_ptr(), st))
+        return out

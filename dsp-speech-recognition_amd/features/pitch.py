@@ -82,33 +82,38 @@ def pitch_detect_frame_sr(frame, rate):
     return list(scores[0])
 
 
+def _rows_on_device(g, flags, bias=MIN_SHIFT, degree=2):
+    """Score rows [T, n_lags] (fp64) through dsp_pitch_rows_batch as a batch of one -> (rows after the call, pitch)."""
+    nat.require_device()
+    lib = nat.load()
+    rows = np.ascontiguousarray(np.asarray(g, dtype=np.float64))
+    if rows.ndim != 2:
+        rows = rows.reshape(len(rows), -1)
+    T, n = rows.shape
+    if T == 0 or n == 0:
+        return rows, np.zeros(0)
+    d_rows = nat.device_array('pitch_rows', rows)
+    d_fo = nat.device_array('pitch_rows_fo', np.array([0, T], dtype=np.int64))
+    d_pitch = nat.SCRATCH.get('pitch_rows_out', T * 8)
+    nat.check(lib.dsp_pitch_rows_batch(d_rows.ptr, d_fo.ptr, 1, n, int(bias), int(degree), int(flags), d_pitch.ptr, None))
+    return (d_rows.download((T, n), np.float64) if flags & 1 else rows), (d_pitch.download((T,), np.float64) if flags & 2 else None)
+
+
 def smooth(g, degree=2):
-    """pitch.py:157-164: in-place running mean over rows [i - degree, i + degree)."""
-    g = np.array(g, dtype=np.float64)
-    n = len(g)
-    for i in range(n):
-        left = i - degree if i - degree >= 0 else 0
-        right = i + degree if i + degree < n else n - 1
-        g[i] = np.mean(g[left:right], axis=0)
-    return g.tolist()
+    """pitch.py:157-164 (in-place running mean over rows [i - degree, i + degree), the rows before i already
+    smoothed), on the device."""
+    rows, _ = _rows_on_device(g, 1, degree=degree)
+    return rows.tolist()
 
 
 def max_pitch(g, bias=20):
-    """pitch.py:166-172."""
-    return [1 / (0.0001 * (bias + int(np.argmax(l)))) for l in g]
+    """pitch.py:166-172: 1 / (1e-4 (bias + first arg-max)) per row, on the device."""
+    return list(_rows_on_device(g, 2, bias=bias)[1])
 
 
 def robust_max_pitch(g, bias=20):
-    """pitch.py:191-206."""
-    C = 50
-    pitch = max_pitch(g, bias)
-    for i in range(1, len(pitch)):
-        if abs(2 * pitch[i] - pitch[i - 1]) < C and pitch[i] < 170:
-            pitch[i] = 2 * pitch[i]
-    for i in range(len(pitch) - 2, 0, -1):
-        if abs(2 * pitch[i] - pitch[i + 1]) < C and pitch[i] < 170:
-            pitch[i] = 2 * pitch[i]
-    return pitch
+    """pitch.py:191-206: max_pitch, then the two octave-repair sweeps, on the device."""
+    return list(_rows_on_device(g, 2 | 4, bias=bias)[1])
 
 
 def pitch_tracks_batch(sig10k, sample_offsets, L, S, rate=10000):
@@ -130,6 +135,32 @@ def pitch_tracks_batch(sig10k, sample_offsets, L, S, rate=10000):
                                          _device_taps(L, rate).ptr, 1, MIN_SHIFT, MAX_SHIFT, d_scores.ptr, None))
     nat.check(lib.dsp_pitch_track_batch(d_scores.ptr, d_fo.ptr, len(so) - 1, n_lags, MIN_SHIFT, 2, d_pitch.ptr, None))
     return d_pitch.download((int(fo[-1]),), np.float64), fo
+
+
+def pitch_tracks_device(d_clips, d_src_off, n_utt, n_samples_bound, rate, L, S, stream=None):
+    """pitch.pitch_detect_sr for clips that are already on the device (fp32, concatenated, `rate` Hz): decimation to
+    10 kHz (dsp_resample_layout_batch + dsp_decimate_batch), scores, smoothing, arg-max and octave repair, nothing
+    leaves the device.  Returns (d_pitch [fp64, one per frame], d_frame_off [B+1]) as library scratch buffers."""
+    lib = nat.load()
+    if rate > 10000:
+        d_so10 = nat.SCRATCH.get('pitch_so10', (n_utt + 1) * 8)
+        d_fo = nat.SCRATCH.get('pitch_fo10', (n_utt + 1) * 8)
+        d_x10 = nat.SCRATCH.get('pitch_x10', max(4, int(n_samples_bound) * 4))
+        nat.check(lib.dsp_resample_layout_batch(d_src_off, n_utt, int(rate), 10000, int(L), int(S), d_so10.ptr, d_fo.ptr, stream))
+        nat.check(lib.dsp_decimate_batch(d_clips, d_src_off, d_so10.ptr, n_utt, int(n_samples_bound), int(rate), 10000, d_x10.ptr, stream))
+        p_x, p_so = d_x10.ptr, d_so10.ptr
+    else:                       # downsampling keeps every sample when the clip is at 10 kHz or below (preprocess.py:21-28)
+        d_fo = nat.SCRATCH.get('pitch_fo10', (n_utt + 1) * 8)
+        nat.check(lib.dsp_resample_layout_batch(d_src_off, n_utt, int(rate), 0, int(L), int(S), None, d_fo.ptr, stream))
+        p_x, p_so = d_clips, d_src_off
+    frames_bound = int(n_samples_bound) // int(S) + n_utt + 1
+    n_lags = MAX_SHIFT - MIN_SHIFT
+    d_scores = nat.SCRATCH.get('pitch_scores', frames_bound * n_lags * 4)
+    d_pitch = nat.SCRATCH.get('pitch_track', frames_bound * 8)
+    nat.check(lib.dsp_pitch_scores_batch(p_x, p_so, d_fo.ptr, n_utt, frames_bound, 0, int(L), int(S), _device_taps(L, 10000).ptr, 1,
+                                         MIN_SHIFT, MAX_SHIFT, d_scores.ptr, stream))
+    nat.check(lib.dsp_pitch_track_batch(d_scores.ptr, d_fo.ptr, n_utt, n_lags, MIN_SHIFT, 2, d_pitch.ptr, stream))
+    return d_pitch, d_fo
 
 
 def pitch_detect_sr(sig, rate, winlen=0.0512, step=0.01):

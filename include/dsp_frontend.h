@@ -345,6 +345,36 @@ int dsp_pitch_scores_batch(const float* d_sig, const int64_t* d_sample_offsets,
 int dsp_pitch_track_batch(const float* d_scores, const int64_t* d_frame_offsets, int32_t n_utt, int32_t n_lags,
                           int32_t bias, int32_t degree, double* d_pitch, void* stream);
 
+/*
+ * The tracker's parts on fp64 score rows [sum T_b, n_lags] (what the reference's helpers take): flags bit 0 =
+ * pitch.smooth(g, degree) in place (pitch.py:157-164), bit 1 = pitch.max_pitch (pitch.py:166-172) into d_pitch, bit 2 =
+ * the octave-repair sweeps of pitch.robust_max_pitch (pitch.py:191-206; needs bit 1).  d_rows is overwritten by the
+ * smoothed rows when bit 0 is set.
+ */
+int dsp_pitch_rows_batch(double* d_rows, const int64_t* d_frame_offsets, int32_t n_utt, int32_t n_lags, int32_t bias,
+                         int32_t degree, int32_t flags, double* d_pitch, void* stream);
+
+/*
+ * Device-side glue of the optional streams of model.py:90-101 (no clip leaves the device):
+ *   dsp_resample_layout_batch  from the sample offsets of a batch: with dst_rate > 0 the lengths preprocess.downsampling
+ *                              (preprocess.py:21-28) leaves of every clip and their exclusive prefix d_dst_offsets[B+1];
+ *                              always the exclusive prefix d_frame_offsets[B+1] of the frame counts of the (decimated)
+ *                              clips at (frame_len, frame_step) (sigproc.py:79-82).  dst_rate = 0: frame offsets only.
+ *   dsp_decimate_batch         the kept samples themselves (the k-th kept index is the first i with
+ *                              i * dst_rate / src_rate > k - 1 + 1e-8, the reference's fp64 test); n_out_bound is an
+ *                              upper bound of the output length (e.g. the input length), the true total is
+ *                              d_dst_offsets[n_utt].
+ *   dsp_model_pitchfeat_batch  [max_len, B, 2] = pitch / 150 and its first difference, zero padded (model.py:90-95,
+ *                              35-50), from dsp_pitch_track_batch's d_pitch.
+ */
+int dsp_resample_layout_batch(const int64_t* d_src_offsets, int32_t n_utt, int64_t src_rate, int64_t dst_rate,
+                              int32_t frame_len, int32_t frame_step, int64_t* d_dst_offsets, int64_t* d_frame_offsets,
+                              void* stream);
+int dsp_decimate_batch(const float* d_in, const int64_t* d_src_offsets, const int64_t* d_dst_offsets, int32_t n_utt,
+                       int64_t n_out_bound, int64_t src_rate, int64_t dst_rate, float* d_out, void* stream);
+int dsp_model_pitchfeat_batch(const double* d_pitch, const int64_t* d_frame_offsets, int32_t n_utt, int32_t max_len,
+                              float* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

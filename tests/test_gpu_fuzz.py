@@ -248,6 +248,55 @@ def test_pitch_scores_batch_and_tracks_vs_oracle():
         assert same.all(), (rate, same.mean())     # measured: every frame identical (parity_measured.json)
 
 
+def test_pitch_helpers_on_the_device_equal_the_oracle():
+    """features.pitch.smooth / max_pitch / robust_max_pitch are batches of one through dsp_pitch_rows_batch: exact
+    against the oracle's restatement of pitch.py:157-206 on random score rows (ties, a one-row input, other degrees)."""
+    import features
+    from features.pitch import smooth, max_pitch, robust_max_pitch
+    from oracle import dsp_oracle
+    rng = np.random.default_rng(8)
+    for T, n, degree in ((57, 180, 2), (1, 180, 2), (2, 7, 2), (40, 65, 1), (33, 130, 3), (5, 180, 4)):
+        g = rng.standard_normal((T, n)) * rng.uniform(0.1, 100)
+        g[T // 2, 3] = g[T // 2, 5] = g[T // 2].max() + 1.0          # a tie: the first index wins
+        with np.errstate(invalid='ignore'), np.testing.suppress_warnings() as sup:
+            sup.filter(RuntimeWarning)
+            want_s = np.asarray(dsp_oracle.smooth(g, degree))
+        got_s = np.asarray(smooth(g, degree))
+        assert got_s.shape == want_s.shape and np.allclose(got_s, want_s, rtol=1e-15, atol=0, equal_nan=True), (T, n, degree)
+        assert np.array_equal(np.asarray(max_pitch(g, 20)), np.asarray(dsp_oracle.max_pitch(g, 20)))
+        assert np.array_equal(np.asarray(robust_max_pitch(g, 20)), np.asarray(dsp_oracle.robust_max_pitch(g, 20)))
+    assert features.smooth is smooth and features.robust_max_pitch is robust_max_pitch
+
+
+@pytest.mark.parametrize('rate', [11025, 16000, 22050, 44100, 48000])
+def test_device_decimation_equals_preprocess_downsampling(rate):
+    """dsp_resample_layout_batch + dsp_decimate_batch against preprocess.downsampling (preprocess.py:21-28) on a ragged
+    batch: every kept sample, every offset, and the frame offsets of the decimated clips."""
+    import torch
+    from features import _native as nat
+    from oracle import dsp_oracle
+    rng = np.random.default_rng(rate)
+    lens = [0, 1, 2, 3, 4, 5, 7, 441, 4410, 4411] + [int(x) for x in rng.integers(1, 30000, 30)]
+    so = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+    x = rng.standard_normal(int(so[-1])).astype(np.float32)
+    dev = torch.device('cuda', 0)
+    d_x, d_so = torch.from_numpy(x).to(dev), torch.from_numpy(so).to(dev)
+    B = len(lens)
+    d_so10 = torch.empty(B + 1, dtype=torch.int64, device=dev)
+    d_fo = torch.empty(B + 1, dtype=torch.int64, device=dev)
+    d_out = torch.full((x.size + 1,), float('nan'), dtype=torch.float32, device=dev)
+    lib = nat.load()
+    L, S = 300, 100
+    nat.check(lib.dsp_resample_layout_batch(d_so.data_ptr(), B, rate, 10000, L, S, d_so10.data_ptr(), d_fo.data_ptr(), None))
+    nat.check(lib.dsp_decimate_batch(d_x.data_ptr(), d_so.data_ptr(), d_so10.data_ptr(), B, x.size, rate, 10000, d_out.data_ptr(), None))
+    torch.cuda.synchronize()
+    so10, fo, out = d_so10.cpu().numpy(), d_fo.cpu().numpy(), d_out.cpu().numpy()
+    want = [np.asarray(dsp_oracle.downsampling(x[so[b]:so[b + 1]], rate, 10000), dtype=np.float32) for b in range(B)]
+    assert np.array_equal(np.diff(so10), [len(w) for w in want])
+    assert np.array_equal(out[:so10[-1]], np.concatenate(want)) and np.isnan(out[so10[-1]:]).all()
+    assert np.array_equal(np.diff(fo), [dsp_oracle.frame_geometry(len(w), L, S)[2] for w in want])
+
+
 def test_long_utterance_takes_the_serial_rule_path():
     """Utterances longer than 2048 VAD frames (20.5 s) do not fit the rule kernel's LDS copy and are
     scanned straight from HBM by one lane: same endpoints as the oracle, mixed in a batch with short
@@ -287,7 +336,7 @@ def test_device_pitch_tracker_equals_the_reference_sequence():
     buffer.  Pitch values are fp64 and must be IDENTICAL."""
     import ctypes as C
     from features import _native as nat
-    from features.pitch import smooth, robust_max_pitch
+    from oracle.dsp_oracle import smooth, robust_max_pitch       # the checker (pitch.py:157-206 restated)
     lib = nat.load()
     rng = np.random.default_rng(77)
     Ts = [1, 2, 3, 4, 5, 17, 64, 150, 2100, 1, 33]

@@ -338,32 +338,39 @@ def test_model_feature_batch_training_path_with_jitter(golden):
     assert ends0[0, 0] - ends[0, 0] == -jit[0, 0] or ends[0, 0] == 0
 
 
-def test_model_feature_batch_optional_streams():
+@pytest.mark.parametrize('rate', [16000, 22050, 44100])
+def test_model_feature_batch_optional_streams(rate):
     """cfg.use_pitch / cfg.use_timefeat of model.py:125-128 in the batched glue: [200, B, 39 + 2 + 2] with the
     streams in the reference's order (mfcc0 | mfcc1 | mfcc2 | pitch0 | pitch1 | amp0 | amp1), each against the
-    oracle's per-utterance functions on the oracle's own trimmed, scaled clip."""
+    oracle's per-utterance functions on the oracle's own trimmed, scaled clip.  At 22.05 kHz the amplitude stream's
+    framing (int(): 661 / 220 samples) differs from the MFCC framing (round half up: 662 / 221); at 22.05 and 44.1 kHz
+    the pitch stream decimates to 10 kHz on the device (preprocess.py:21-28)."""
     from features.model_glue import ModelFeatureBatch
     from golden_cases import make_signal
     from conftest import normwise, record
-    clips = [make_signal(('vad', 120 + i, 20000 + 3000 * i, 16000, 0.6)) for i in range(3)]
+    clips = [make_signal(('vad', 120 + i, int((20000 + 3000 * i) * rate / 16000), rate, 0.6)) for i in range(3)]
     so = np.concatenate(([0], np.cumsum([len(c) for c in clips]))).astype(np.int64)
-    mfb = ModelFeatureBatch(rate=16000)
+    mfb = ModelFeatureBatch(rate=rate)
     base, len_b, _ = mfb.run(np.concatenate(clips), so)
     inp, len0, ends = mfb.run(np.concatenate(clips), so, use_pitch=True, use_timefeat=True)
     assert inp.shape == (200, 3, 43) and np.array_equal(len0, len_b)
     got = inp.cpu().numpy()
     assert np.array_equal(got[:, :, :39], base.cpu().numpy())
     for b, c in enumerate(clips):
-        lo, hi = dsp_oracle.basic_endpoint_detection(c, 16000)
+        lo, hi = dsp_oracle.basic_endpoint_detection(c, rate)
         sound = dsp_oracle.model_endpoint_scale(c, lo, hi)
-        a0, a1 = dsp_oracle.model_feature_extract_timespace(sound, 16000)
+        a0, a1 = dsp_oracle.model_feature_extract_timespace(sound, rate)
         n0, n1 = min(len(a0), 200), min(len(a1), 200)
         assert record('model_batch_timefeat', normwise(got[:n0, b, 41], a0[:n0, 0])) <= 1e-4
+        assert not got[n0:, b, 41].any()                     # the stream's own frame count, zero padded beyond
         assert normwise(got[:n1, b, 42], a1[:n1, 0]) <= 1e-4 and not got[n1:, b, 42].any()
-        p0, p1 = dsp_oracle.model_feature_extract_pitch(sound, 16000)
-        m0 = min(len(p0), 200)
+        p0, p1 = dsp_oracle.model_feature_extract_pitch(sound, rate)
+        m0, m1 = min(len(p0), 200), min(len(p1), 200)
         same = np.isclose(got[:m0, b, 39], p0[:m0, 0], rtol=1e-5, atol=1e-6)
         assert same.mean() >= 0.98, (b, same.mean())       # fp32 clip vs fp64 clip: an arg-max may flip on a near tie
+        assert not got[m0:, b, 39].any() and not got[m1:, b, 40].any()
+        # the difference stream is the difference of the stream it sits beside, whatever the arg-max decided
+        assert np.allclose(got[:m1, b, 40], got[1:m1 + 1, b, 39] - got[:m1, b, 39], rtol=0, atol=2e-6)
 
 
 def test_dense_feature_call_is_hip_graph_capturable():
