@@ -794,7 +794,7 @@ SegWork seg_work_layout(int32_t n_utt, int64_t n_frames_bound, int32_t C) {
     w.tile = w.stats + pad((size_t)n_utt * 2 * sizeof(double));
     w.goff = w.tile + pad(((size_t)n_utt + 1) * sizeof(int64_t));
     w.gutt = w.goff + pad(((size_t)n_utt + 1) * sizeof(int32_t));
-    w.tutt = w.gutt + pad(((size_t)(n_frames_bound >> 3) + (size_t)n_utt) * sizeof(int32_t));
+    w.tutt = w.gutt + pad(((size_t)(n_frames_bound >> 2) + (size_t)n_utt) * sizeof(int32_t));   // 4-frame groups (NFFT = 1536) at most
     w.cep = w.tutt + pad(((size_t)(n_frames_bound >> DT_SHIFT) + (size_t)n_utt) * sizeof(int32_t));
     w.total = w.cep + pad((size_t)n_frames_bound * (size_t)C * sizeof(float));
     return w;
@@ -814,7 +814,7 @@ int dsp_mfcc_delta_segments_batch(const dsp_plan* plan, const void* d_wave, int 
                                   float* d_out, void* stream) {
     const int unit_variance = flags & DSP_SEG_UNIT_VARIANCE;
     if (!plan || !d_out || !d_work || !d_segments) return fail(DSP_EINVAL, "dsp_mfcc_delta_segments_batch: NULL argument");
-    if (delta_n < 1) return fail(DSP_EINVAL, "N must be an integer >= 1");  // base.py:71-72
+    if (delta_n < 0) return fail(DSP_EINVAL, "N must be an integer >= 1 (or 0: cepstra only)");  // base.py:71-72
     int rc = check_geom(d_wave, wave_dtype, d_sample_offsets, d_frame_offsets, n_utt, n_frames_bound, 0);
     if (rc != DSP_OK) return rc;
     {
@@ -825,10 +825,13 @@ int dsp_mfcc_delta_segments_batch(const dsp_plan* plan, const void* d_wave, int 
     const int C = plan->C;
     const size_t lds = ((size_t)(DT_TILE + 4 * delta_n) + (size_t)(DT_TILE + 2 * delta_n)) * C * sizeof(float);
     BatchGeom bg = make_geom(d_sample_offsets, d_frame_offsets, n_utt, n_frames_bound, 0, plan->L, plan->S);
-    // Served by the NFFT = 512 kernel on buffers it can read in place; everything else (and unit variance without
-    // appendEnergy, where the scaling does not reduce to a shift of c0) reports 1: "use the trimmed-copy path".
-    if (g_force_generic || !plan->d_fast || C <= 0 || lds > 64 * 1024 || !fast512_applicable(plan, bg, d_wave, wave_dtype) ||
-        (unit_variance && !plan->append_energy) || (n_frames_bound >> 3) + n_utt > 0x3fffffff)
+    // Served by the NFFT = 512 and NFFT = 1536 kernels on buffers they can read in place; everything else (and unit
+    // variance without appendEnergy, where the scaling does not reduce to a shift of c0) reports 1: "use the
+    // trimmed-copy path".
+    const bool k512 = plan->d_fast && fast512_applicable(plan, bg, d_wave, wave_dtype);
+    const bool k1536 = !k512 && plan->d_fast1536 && fast1536_applicable(plan, bg, d_wave, wave_dtype);
+    if (g_force_generic || (!k512 && !k1536) || C <= 0 || lds > 64 * 1024 ||
+        (unit_variance && !plan->append_energy) || (n_frames_bound >> 2) + n_utt > 0x3fffffff)
         return 1;
     const SegWork w = seg_work_layout(n_utt, n_frames_bound, C);
     if (work_bytes < w.total) return fail(DSP_EINVAL, "work buffer too small (%zu < %zu bytes)", work_bytes, w.total);
@@ -837,18 +840,20 @@ int dsp_mfcc_delta_segments_batch(const dsp_plan* plan, const void* d_wave, int 
     double* stats = unit_variance ? reinterpret_cast<double*>(wp + w.stats) : nullptr;
     int64_t* tile_off = reinterpret_cast<int64_t*>(wp + w.tile);
     DspRaggedTables pre;
-    pre.shift = 3;
+    pre.shift = k512 ? 3 : 2;
     pre.group_off = reinterpret_cast<int32_t*>(wp + w.goff);
     pre.group_utt = reinterpret_cast<int32_t*>(wp + w.gutt);
-    float* cep = reinterpret_cast<float*>(wp + w.cep);
+    float* cep = delta_n >= 1 ? reinterpret_cast<float*>(wp + w.cep) : d_out;   // cepstra only: straight into the result
     // one small launch: group tables of the MFCC kernel, tile table of the delta pass, statistics zeroed -- unless
     // dsp_endpoint_layout_segments_batch has already left all of that in d_work
     if (!(flags & DSP_SEG_TABLES_READY))
-        f512_build_group_tables(d_frame_offsets, n_utt, 3, pre.group_off, pre.group_utt, st, tile_off, stats);
+        f512_build_group_tables(d_frame_offsets, n_utt, pre.shift, pre.group_off, pre.group_utt, st, tile_off, stats);
     bg.seg = d_segments;
     bg.stats = stats;
-    rc = fast512_launch(plan, d_wave, wave_dtype, bg, cep, (int64_t)C, st, &pre);
+    rc = k512 ? fast512_launch(plan, d_wave, wave_dtype, bg, cep, (int64_t)C, st, &pre)
+              : fast1536_launch(plan, d_wave, wave_dtype, bg, cep, (int64_t)C, st, &pre);
     if (rc != DSP_OK) return fail(rc < 0 ? rc : DSP_EHIP, "fused kernel launch failed");
+    if (delta_n == 0) return DSP_OK;    // (unit variance: c0 still lacks -ln(var); dsp_model_finalize_segments_batch applies it)
     BatchGeom dg;
     memset(&dg, 0, sizeof(dg));
     dg.frame_off = d_frame_offsets;
@@ -892,14 +897,15 @@ int dsp_endpoint_layout_segments_batch(const int32_t* d_endpoints, const int64_t
         return fail(DSP_EINVAL, "dsp_endpoint_layout_segments_batch: bad arguments");
     if (!(cfg_step > 0.0) || !(rate > 0.0) || n_frames_bound <= 0)
         return fail(DSP_EINVAL, "dsp_endpoint_layout_segments_batch: step, rate, n_frames_bound must be > 0");
-    if ((n_frames_bound >> 3) + n_utt > 0x3fffffff)   // the kernel's group and tile counters are int32 (as dsp_mfcc_delta_segments_batch checks)
+    if ((n_frames_bound >> 2) + n_utt > 0x3fffffff)   // the kernel's group and tile counters are int32 (as dsp_mfcc_delta_segments_batch checks)
         return fail(DSP_EINVAL, "dsp_endpoint_layout_segments_batch: batch too large");
     const SegWork w = seg_work_layout(n_utt, n_frames_bound, plan->C);
     if (work_bytes < w.total) return fail(DSP_EINVAL, "work buffer too small (%zu < %zu bytes)", work_bytes, w.total);
     char* wp = static_cast<char*>(d_work);
     endpoint_layout_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(
         d_endpoints, d_sample_offsets, n_utt, cfg_step, rate, plan->L, plan->S, d_jitter, d_segments, d_dst_offsets,
-        d_frame_offsets, 3, reinterpret_cast<int32_t*>(wp + w.goff), reinterpret_cast<int32_t*>(wp + w.gutt),
+        d_frame_offsets, plan->d_fast ? 3 : 2 /* frames per group: 8 (NFFT = 512 kernel) or 4 (NFFT = 1536) */,
+        reinterpret_cast<int32_t*>(wp + w.goff), reinterpret_cast<int32_t*>(wp + w.gutt),
         reinterpret_cast<int64_t*>(wp + w.tile), reinterpret_cast<double*>(wp + w.stats),
         reinterpret_cast<int32_t*>(wp + w.tutt));
     HIP_TRY(hipGetLastError());
@@ -918,6 +924,24 @@ int dsp_model_finalize_batch(const float* d_mfcc, int64_t ld_in, const int64_t* 
     if (lds > 64 * 1024) return fail(DSP_EINVAL, "max_len * C too large for the LDS tile (%zu bytes)", lds);
     model_finalize_kernel<<<n_utt, 256, lds, (hipStream_t)stream>>>(d_mfcc, ld_in, d_frame_offsets, n_utt, C, N,
                                                                    max_len, d_out, d_len0);
+    HIP_TRY(hipGetLastError());
+    return DSP_OK;
+}
+
+int dsp_model_finalize_segments_batch(const float* d_mfcc, int64_t ld_in, const int64_t* d_frame_offsets,
+                                      const int64_t* d_segments, const void* d_work, int32_t n_utt, int32_t C, int32_t N,
+                                      int32_t max_len, float* d_out, int32_t* d_len0, void* stream) {
+    if (!d_mfcc || !d_frame_offsets || !d_segments || !d_work || !d_out || !d_len0 || n_utt <= 0)
+        return fail(DSP_EINVAL, "dsp_model_finalize_segments_batch: bad arguments");
+    if (N < 1) return fail(DSP_EINVAL, "N must be an integer >= 1");  // base.py:71-72
+    if (C <= 0 || C > 32 || max_len <= 0) return fail(DSP_EINVAL, "need 0 < C <= 32 and max_len > 0");
+    if (ld_in == 0) ld_in = C;
+    if (ld_in < C) return fail(DSP_EINVAL, "ld_in %lld < C %d", (long long)ld_in, C);
+    const size_t lds = ((size_t)(max_len + 2 * N) + (size_t)(max_len + N)) * C * sizeof(float);
+    if (lds > 64 * 1024) return fail(DSP_EINVAL, "max_len * C too large for the LDS tile (%zu bytes)", lds);
+    // the statistics sit at the start of the work buffer of dsp_mfcc_delta_segments_batch (seg_work_layout)
+    model_finalize_kernel<<<n_utt, 256, lds, (hipStream_t)stream>>>(d_mfcc, ld_in, d_frame_offsets, n_utt, C, N, max_len, d_out, d_len0,
+                                                                   d_segments, static_cast<const double*>(d_work));
     HIP_TRY(hipGetLastError());
     return DSP_OK;
 }

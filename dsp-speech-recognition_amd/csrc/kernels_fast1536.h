@@ -76,6 +76,11 @@ __device__ __forceinline__ F512Group f1536_locate(const F1536Params& P, const Ba
         g.t0 = (G - P.group_off[g.utt]) * 4;
         g.s0 = bg.sample_off[g.utt];
         g.nsamp = (int)(bg.sample_off[g.utt + 1] - g.s0);
+        if (bg.seg != nullptr) {   // the utterance is a segment of that range, read in place (kernels_fast512.h)
+            const int64_t lo = bg.seg[2 * g.utt];
+            g.nsamp = (int)(bg.seg[2 * g.utt + 1] - lo);
+            g.s0 += lo;
+        }
         g.row0 = bg.frame_off[g.utt];
         g.T = (int)(bg.frame_off[g.utt + 1] - g.row0);
     } else {
@@ -294,6 +299,19 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES > 8 ? 3 : 2)) void mfcc1536_kern
         // groups entirely inside their utterance stage without per-vector bookkeeping (kernels_fast512.h)
         const bool fast_stage = base + NSTAGE * 256 <= nsamp;
         const int d = (RAGGED && !fast_stage) ? (int)(g0 & 3) : 0;
+        // Unit-variance statistics of segments read in place (bg.stats, as in kernels_fast512.h): every group adds the sums
+        // of its own share [base, base + 4 S) of the utterance -- the last group everything up to the end -- of (x - x0)
+        // and (x - x0)^2, x0 = the utterance's first sample.
+        float st_s = 0.f, st_q = 0.f, st_ref = 0.f;
+        int st_lim = 0;
+        bool do_stats = false;
+        if constexpr (RAGGED) {
+            do_stats = bg.stats != nullptr && nsamp > 0;
+            if (do_stats) {
+                st_ref = dsp_load_sample<DTYPE>(wave, grp.s0);
+                st_lim = t0 + 4 >= T ? nsamp : base + 4 * P.S;
+            }
+        }
 
         // ---- stage 3 S + 1536 (+ d) samples: 16 B loads, pre-emphasis, zero fill ----
         if (fast_stage) {
@@ -316,6 +334,24 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES > 8 ? 3 : 2)) void mfcc1536_kern
                 y.z = fmaf(-P.preemph, x[1], x[2]);
                 y.w = fmaf(-P.preemph, x[2], x[3]);
                 if (lane + 64 * r < span_vec) *reinterpret_cast<float4*>(wbuf + 4 * lane + 256 * r) = y;
+                if constexpr (RAGGED) {
+                    if (do_stats) {
+                        const int round_in = st_lim - (base + 256 * r);    // samples of this round inside the share (wave-uniform)
+                        if (round_in >= 256) {
+                            const float d0 = x[0] - st_ref, d1 = x[1] - st_ref, d2 = x[2] - st_ref, d3 = x[3] - st_ref;
+                            st_s += (d0 + d1) + (d2 + d3);
+                            st_q = fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, fmaf(d3, d3, st_q))));
+                        } else if (round_in > 0) {
+                            const int left_in_share = round_in - 4 * lane;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float dl = k < left_in_share ? x[k] - st_ref : 0.f;
+                                st_s += dl;
+                                st_q = fmaf(dl, dl, st_q);
+                            }
+                        }
+                    }
+                }
             }
         } else {
             const int64_t a0 = g0 - d;
@@ -343,6 +379,15 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES > 8 ? 3 : 2)) void mfcc1536_kern
                 y.z = fmaf(-P.preemph, x[1], x[2]);
                 y.w = fmaf(-P.preemph, x[2], x[3]);
                 if constexpr (RAGGED) {
+                    if (do_stats) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const bool in = v < span_vec && rel + k >= base && rel + k < st_lim;
+                            const float dl = in ? x[k] - st_ref : 0.f;
+                            st_s += dl;
+                            st_q = fmaf(dl, dl, st_q);
+                        }
+                    }
                     if (rel + 0 == 0) y.x = x[0];
                     if (rel + 1 == 0) y.y = x[1];
                     if (rel + 2 == 0) y.z = x[2];
@@ -359,6 +404,19 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES > 8 ? 3 : 2)) void mfcc1536_kern
                     y.w = __uint_as_float(__float_as_uint(y.w) & m);
                 }
                 if (v < span_vec) *reinterpret_cast<float4*>(wbuf + 4 * v) = y;
+            }
+        }
+        if constexpr (RAGGED) {
+            if (do_stats) {
+                float ws = st_s, wq = st_q;
+                ws += dpp_f32<0xB1>(ws);  wq += dpp_f32<0xB1>(wq);     // quad_perm [1,0,3,2]
+                ws += dpp_f32<0x4E>(ws);  wq += dpp_f32<0x4E>(wq);     // quad_perm [2,3,0,1]
+                ws += dpp_f32<0x141>(ws); wq += dpp_f32<0x141>(wq);    // row_half_mirror
+                ws += dpp_f32<0x140>(ws); wq += dpp_f32<0x140>(wq);    // row_mirror
+                if ((lane & 15) == 0) {
+                    unsafeAtomicAdd(bg.stats + 2 * grp.utt, (double)ws);
+                    unsafeAtomicAdd(bg.stats + 2 * grp.utt + 1, (double)wq);
+                }
             }
         }
         F512_FENCE();

@@ -1031,18 +1031,43 @@ __global__ __launch_bounds__(64) void timefeat_finalize_kernel(const double* __r
 __global__ __launch_bounds__(256) void model_finalize_kernel(const float* __restrict__ mfcc, int64_t ld_in,
                                                              const int64_t* __restrict__ frame_off, int32_t n_utt,
                                                              int32_t C, int32_t N, int32_t max_len,
-                                                             float* __restrict__ out, int32_t* __restrict__ len0) {
+                                                             float* __restrict__ out, int32_t* __restrict__ len0,
+                                                             // cepstra of segments read IN PLACE (dsp_mfcc_delta_segments_batch,
+                                                             // delta_n = 0, unit variance): c0 still lacks the -ln(var) of
+                                                             // model.py:62-63 -- applied here, at every read, from the sums
+                                                             // the MFCC kernel left (frames of zero energy keep ln(eps))
+                                                             const int64_t* __restrict__ seg = nullptr,
+                                                             const double* __restrict__ stats = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float fin_smem[];
     __shared__ double red[4];
     __shared__ double s_mu[32], s_inv[32];
+    __shared__ double s_shift;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int64_t base = frame_off[b];
     const int T = (int)(frame_off[b + 1] - base);
     const int keep = T < max_len ? T : max_len;
-    const float* in = mfcc + base * ld_in;
+    const float* in_raw = mfcc + base * ld_in;
+    if (tid == 0) {
+        double sh = 0.0;
+        if (stats != nullptr) {
+            const double n = (double)(seg[2 * b + 1] - seg[2 * b]);
+            if (n > 0.0) {
+                const double mean = stats[2 * b] / n;
+                const double var = stats[2 * b + 1] / n - mean * mean;
+                sh = var > 0.0 ? log(var) : 0.0;                      // zero variance: sklearn scales by 1
+            }
+        }
+        s_shift = sh;
+    }
+    __syncthreads();
+    const double shift = s_shift;
+    auto in = [&](int64_t idx, int c) -> double {                      // element (row idx / ld_in, column c) with the shift of c0
+        const float v = in_raw[idx];
+        return (c == 0 && stats != nullptr && v != -36.04365338911715f) ? (double)v - shift : (double)v;
+    };
     // scalar mean of the block
     double s = 0.0;
-    for (int i = tid; i < T * C; i += 256) s += (double)in[(int64_t)(i / C) * ld_in + (i % C)];
+    for (int i = tid; i < T * C; i += 256) s += in((int64_t)(i / C) * ld_in + (i % C), i % C);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if ((tid & 63) == 0) red[tid >> 6] = s;
@@ -1053,13 +1078,13 @@ __global__ __launch_bounds__(256) void model_finalize_kernel(const float* __rest
     const int wid = tid >> 6, lane = tid & 63;
     for (int c = wid; c < C; c += 4) {
         double a = 0.0;
-        for (int t = lane; t < T; t += 64) a += (double)(float)((double)in[(int64_t)t * ld_in + c] - gmean);
+        for (int t = lane; t < T; t += 64) a += (double)(float)(in((int64_t)t * ld_in + c, c) - gmean);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
         const double mu = T > 0 ? a / (double)T : 0.0;
         double v = 0.0;
         for (int t = lane; t < T; t += 64) {
-            const double dlt = (double)(float)((double)in[(int64_t)t * ld_in + c] - gmean) - mu;
+            const double dlt = (double)(float)(in((int64_t)t * ld_in + c, c) - gmean) - mu;
             v += dlt * dlt;
         }
 #pragma unroll
@@ -1076,7 +1101,7 @@ __global__ __launch_bounds__(256) void model_finalize_kernel(const float* __rest
     float* sx = fin_smem;                       // [max_len + 2 N, C]
     float* sd1 = fin_smem + (size_t)(max_len + 2 * N) * C;   // [max_len + N, C]
     for (int i = tid; i < nx * C; i += 256)
-        sx[i] = (float)((double)in[(int64_t)(i / C) * ld_in + (i % C)] - gmean);
+        sx[i] = (float)(in((int64_t)(i / C) * ld_in + (i % C), i % C) - gmean);
     __syncthreads();
     double den = 0.0;
     for (int n = 1; n <= N; ++n) den += (double)n * n;

@@ -86,6 +86,7 @@ SIGNATURES = {
     'dsp_decimate_batch': (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_i64, c_vp, c_vp]),
     'dsp_model_pitchfeat_batch': (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     'dsp_model_finalize_batch': (C.c_int, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    'dsp_model_finalize_segments_batch': (C.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
 }
 
 _lib = None

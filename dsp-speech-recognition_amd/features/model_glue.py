@@ -169,15 +169,26 @@ class ModelFeatureBatch:
         stream = torch.cuda.current_stream(dev)
         if layout is None:       # this call consumes the layout's tables before it returns: a cached one is safe
             layout = self.pipe._cached_layout(sample_offsets, 0)
-        (d_m0, lay), _, _ = self.pipe.run(waves, delta_n=0, download=False, layout=layout, jitter=jitter)
+        # the clips are read where they lie (no trimmed fp32 copy): the MFCC kernel accumulates the unit-variance
+        # statistics, the finalize kernel applies them to c0 as it reads
+        (d_m0, lay), _, _ = self.pipe.run(waves, delta_n=0, download=False, layout=layout, jitter=jitter, defer_c0_shift=True)
         B, C = lay.n_utt, self.pipe.features.C
         inp = torch.empty((self.max_len, B, 3 * C), dtype=torch.float32, device=dev)
         len0 = torch.empty(B, dtype=torch.int32, device=dev)
         # host input: the pipeline ran on the legacy default stream, which orders against `stream`
         st = _stream_ptr(stream) if _is_device_tensor(waves) else None
-        nat.check(lib.dsp_model_finalize_batch(d_m0.ptr, C, lay.d_frame_off.ptr, B, C, self.delta_n, self.max_len,
-                                               inp.data_ptr(), len0.data_ptr(), st))
+        if lay.c0_shift_pending:
+            nat.check(lib.dsp_model_finalize_segments_batch(d_m0.ptr, C, lay.d_frame_off.ptr, lay.d_seg.ptr, lay.d_work.ptr, B, C,
+                                                            self.delta_n, self.max_len, inp.data_ptr(), len0.data_ptr(), st))
+        else:
+            nat.check(lib.dsp_model_finalize_batch(d_m0.ptr, C, lay.d_frame_off.ptr, B, C, self.delta_n, self.max_len,
+                                                   inp.data_ptr(), len0.data_ptr(), st))
         extra = []
+        if (use_pitch or use_timefeat) and lay.c0_shift_pending:
+            # the optional streams work on the trimmed, scaled clips themselves: make that copy now (model.py:62-63)
+            wave_ptr, wave_dtype = self.pipe._last_wave
+            nat.check(lib.dsp_trim_scale_batch(wave_ptr, wave_dtype, lay.vad.p_sample, lay.d_seg.ptr, lay.d_dst_off.ptr,
+                                               B, 1, lay.d_trim.ptr, st))
         if use_pitch:
             extra.append(self._pitch_streams(lay, st, dev))
         if use_timefeat:

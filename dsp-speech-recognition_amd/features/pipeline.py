@@ -97,7 +97,8 @@ class PipelineLayout:
         self.features = _DeviceLayout(B, self.d_dst_off, self.d_frame_off, self.frames_bound)
         # scratch of the in-place path (dsp_mfcc_delta_segments_batch): tables, statistics, dense cepstra
         self.d_work = None
-        if delta_n >= 1:
+        self.c0_shift_pending = False          # set by launch(): cepstra-only output read in place, unit variance not yet applied
+        if delta_n >= 0:
             import ctypes as C
             nbytes = C.c_size_t(0)
             nat.check(nat.load().dsp_segments_workspace_bytes(fp.plan.handle, B, max(self.frames_bound, 1), C.byref(nbytes)))
@@ -144,14 +145,20 @@ class VadMfccPipeline:
         cache[key] = lay               # most recently used last
         return lay
 
-    def launch(self, d_wave, wave_dtype, lay, d_out, stream=None, d_jitter=None):
+    def launch(self, d_wave, wave_dtype, lay, d_out, stream=None, d_jitter=None, defer_c0_shift=False):
         """Queue the whole pipeline on `stream` (raw pointers, no host synchronisation, no allocation):
-        features land in `d_out` ([lay.frames_bound, D] fp32, rows packed by lay.d_frame_off)."""
+        features land in `d_out` ([lay.frames_bound, D] fp32, rows packed by lay.d_frame_off).
+        ``defer_c0_shift`` (cepstra only, unit variance): the caller applies the -ln(var) of c0 itself
+        (dsp_model_finalize_segments_batch does, from the statistics in lay.d_work) -- then the clips are read in
+        place for delta_n = 0 as well and ``lay.c0_shift_pending`` says so; otherwise cepstra-only unit-variance
+        output takes the trimmed, scaled copy."""
         lib = nat.load()
         st = _stream_ptr(stream)
         ep, fp = self.endpoint, self.features
         ep.run_raw(d_wave, wave_dtype, lay.vad, lay.d_amp.ptr, lay.d_zcr.ptr, lay.d_ep.ptr, st)
-        in_place = lay.d_work is not None and not self.copy_trimmed
+        lay.c0_shift_pending = False
+        in_place = lay.d_work is not None and not self.copy_trimmed and \
+            (lay.delta_n >= 1 or not self.unit_variance or defer_c0_shift)
         if in_place:      # one launch: segments, offsets AND the tables / zeroed statistics of the in-place feature stage
             nat.check(lib.dsp_endpoint_layout_segments_batch(lay.d_ep.ptr, lay.vad.p_sample, lay.n_utt, float(ep.step),
                                                              float(ep.rate), d_jitter, lay.d_seg.ptr, lay.d_dst_off.ptr,
@@ -168,6 +175,7 @@ class VadMfccPipeline:
                                                    (1 if self.unit_variance else 0) | 2, lay.d_work.ptr,
                                                    lay.d_work.nbytes, d_out, st)
             if rc == nat.OK:
+                lay.c0_shift_pending = bool(lay.delta_n == 0 and self.unit_variance)
                 return
             if rc != 1:                      # 1 = "not served in place": take the copy below
                 nat.check(rc)
@@ -175,7 +183,7 @@ class VadMfccPipeline:
                                            lay.n_utt, 1 if self.unit_variance else 0, lay.d_trim.ptr, st))
         fp.run_raw(lay.d_trim.ptr, nat.WAVE_F32, lay.features, d_out, lay.delta_n, st)
 
-    def run(self, waves, sample_offsets=None, delta_n=2, download=True, layout=None, jitter=None):
+    def run(self, waves, sample_offsets=None, delta_n=2, download=True, layout=None, jitter=None, defer_c0_shift=False):
         """waves: 1-D host array (int16 or float) or torch-ROCm tensor (int16 / float32) of concatenated
         utterances; ``layout`` = a PipelineLayout from ``prepare`` (then sample_offsets and delta_n are taken
         from it).
@@ -215,7 +223,8 @@ class VadMfccPipeline:
                                               device=waves.device))
         else:
             d_out = nat.DeviceBuffer(max(lay.frames_bound, 1) * lay.D * 4)  # owned by the result
-        self.launch(d_wave.ptr, dtype, lay, d_out.ptr, stream, d_jit)
+        self._last_wave = (d_wave.ptr, dtype)      # (ModelFeatureBatch's optional streams trim the same buffer again)
+        self.launch(d_wave.ptr, dtype, lay, d_out.ptr, stream, d_jit, defer_c0_shift=defer_c0_shift and not download)
         if not download:
             return (d_out, lay), None, None
         st = _stream_ptr(stream)

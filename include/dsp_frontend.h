@@ -250,7 +250,11 @@ int dsp_trim_scale_batch(const void* d_wave, int wave_dtype, const int64_t* d_sa
  * sums the MFCC kernel accumulates while it stages the samples.  d_work: caller-owned scratch of
  * dsp_segments_workspace_bytes() bytes (tables, statistics, dense cepstra): no pooled workspace, no allocation, the call
  * is a fixed sequence of three launches on `stream` and can be captured into a HIP graph.
- * Returns 1 (not an error) when the plan / buffer is not served in place (no NFFT = 512 fast path, misaligned buffer,
+ * Served by the NFFT = 512 AND the NFFT = 1536 fused kernels (the size model.py:74 uses).  delta_n = 0: cepstra only,
+ * written straight to d_out [sum T, C] (model.py:66-88 wants delta(3) of the MEAN-REMOVED cepstra, which is
+ * dsp_model_finalize_segments_batch's job); with DSP_SEG_UNIT_VARIANCE the c0 column then still lacks its -ln(var) --
+ * the statistics stay at the start of d_work and dsp_model_finalize_segments_batch applies the shift as it reads.
+ * Returns 1 (not an error) when the plan / buffer is not served in place (no fused kernel, misaligned buffer,
  * unit variance without appendEnergy): use dsp_trim_scale_batch + dsp_mfcc_delta_batch then.
  */
 #define DSP_SEG_UNIT_VARIANCE 1   /* flags: the clips count as divided by their standard deviation (see above) */
@@ -312,6 +316,12 @@ int dsp_model_finalize_batch(const float* d_mfcc, int64_t ld_in, const int64_t* 
  * (endpoint.amplitude_feature, endpoint.py:128-131, through sklearn scale: population std, 0 -> 1), column 1 =
  * its first difference (model.py:29-33, T - 1 rows), both zero padded / truncated to max_len (model.py:35-50).
  */
+/* dsp_model_finalize_batch for cepstra of segments read in place (dsp_mfcc_delta_segments_batch, delta_n = 0, same
+   d_segments and d_work): with the unit-variance statistics in d_work, c0 gets its -ln(var) (model.py:62-63) at every
+   read -- frames of exactly zero energy keep ln(eps), base.py:26 -- before the mean, the deltas and the z-score. */
+int dsp_model_finalize_segments_batch(const float* d_mfcc, int64_t ld_in, const int64_t* d_frame_offsets,
+                                      const int64_t* d_segments, const void* d_work, int32_t n_utt, int32_t C, int32_t N,
+                                      int32_t max_len, float* d_out, int32_t* d_len0, void* stream);
 int dsp_model_timefeat_batch(const double* d_amp_sum, const int64_t* d_frame_offsets, int32_t n_utt,
                              int32_t frame_len, int32_t max_len, float* d_out, void* stream);
 

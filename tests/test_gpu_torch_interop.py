@@ -403,3 +403,38 @@ def test_dense_feature_call_is_hip_graph_capturable():
     torch.cuda.synchronize()
     ref, _ = plan.mfcc_batch(waves)
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize('rate', [44100, 48000, 16000])
+def test_model_feature_batch_reads_the_clips_in_place(rate):
+    """The production transform (NFFT = 1536, model.py:74) without the trimmed fp32 copy: the feature kernel reads
+    sig[left:right] where it lies and accumulates the unit-variance statistics, the finalize kernel applies -ln(var) to
+    c0 as it reads (dsp_mfcc_delta_segments_batch with delta_n = 0 + dsp_model_finalize_segments_batch).  Same
+    [200, B, 39] as the trimmed / scaled copy path, and as the oracle's per-utterance pipeline -- including a clip
+    with digital silence inside the detected segment (frames of zero energy keep ln(eps))."""
+    import torch
+    from features.model_glue import ModelFeatureBatch
+    from golden_cases import make_signal
+    from conftest import normwise
+    clips = [make_signal(('vad', 400 + i, int((22000 + 2500 * i) * rate / 16000), rate, 0.6)) for i in range(5)]
+    hole = make_signal(('vad', 410, int(26000 * rate / 16000), rate, 0.6)).copy()
+    mid = int(np.argmax(np.abs(hole.astype(np.int32))))
+    hole[mid - int(0.03 * rate):mid + int(0.03 * rate)] = 0
+    clips.append(hole)
+    so = np.concatenate(([0], np.cumsum([len(c) for c in clips]))).astype(np.int64)
+    flat = torch.from_numpy(np.concatenate(clips)).cuda()
+    mfb = ModelFeatureBatch(rate=rate)
+    lay = mfb.pipe.prepare(so, delta_n=0)
+    inp, len0, ends = mfb.run(flat, layout=lay)
+    assert lay.c0_shift_pending, 'the in-place path was not taken'
+    ref_mfb = ModelFeatureBatch(rate=rate)
+    ref_mfb.pipe.copy_trimmed = True
+    inp_c, len_c, ends_c = ref_mfb.run(flat, so)
+    assert np.array_equal(len0, len_c) and np.array_equal(ends, ends_c)
+    got, want = inp.cpu().numpy(), inp_c.cpu().numpy()
+    assert np.isfinite(got).all()
+    for b in range(len(clips)):
+        assert normwise(got[:, b], want[:, b]) <= 5e-5, (b, normwise(got[:, b], want[:, b]))
+        (m0, m1, m2), n = dsp_oracle.model_pipeline(clips[b], rate)
+        ref = np.concatenate([m0, m1, m2], axis=1)[:200]
+        assert len0[b] == min(n, 200) and normwise(got[:len(ref), b], ref) <= 1e-4, (b, normwise(got[:len(ref), b], ref))
