@@ -184,10 +184,22 @@ def model_path(dev, batch=512):
         with torch.no_grad():
             logits = head(inp, len0)
     torch.cuda.synchronize(dev)
-    reps, t_fe, t_clf = 5, 0.0, 0.0
-    for _ in range(reps):
+    reps, t_eager = 5, 0.0
+    for _ in range(reps):      # the per-call form: Python launches, result tensors allocated, lengths downloaded
         t0 = time.perf_counter()
         inp, len0, _ = mfb.run(src, layout=lay)               # ends with a host synchronisation (downloads the lengths)
+        t_eager += time.perf_counter() - t0
+    # the deployment form: the same launches captured once into a HIP graph over pre-allocated buffers
+    # (ModelFeatureBatch.capture); one replay + one synchronisation per batch
+    graph = mfb.capture(src, lay)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize(dev)
+    t_fe, t_clf = 0.0, 0.0
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        inp, d_len0 = graph.replay()
+        len0 = d_len0.cpu().numpy()                            # the lengths the classifier packs by: the one host synchronisation
         t1 = time.perf_counter()
         with torch.no_grad():
             logits = head(inp, len0)
@@ -195,11 +207,12 @@ def model_path(dev, batch=512):
         t2 = time.perf_counter()
         t_fe += t1 - t0
         t_clf += t2 - t1
-    t_fe, t_clf = t_fe / reps, t_clf / reps
+    t_fe, t_clf, t_eager = t_fe / reps, t_clf / reps, t_eager / reps
     return {'workload': f'configs[4]: {batch} int16 clips of 1-2 s at 44.1 kHz ({int(so[-1])} samples) resident on the '
                         f'device -> model.py feature pipeline -> [200, {batch}, 39] -> 3-layer bidirectional GRU(200) '
                         f'classifier forward (random weights)',
-            'front_end_ms': t_fe * 1e3, 'classifier_ms': t_clf * 1e3, 'utterances_per_s': batch / (t_fe + t_clf),
+            'front_end_ms': t_fe * 1e3, 'front_end_form': 'HIP graph replay of the captured launches + download of the 512 lengths',
+            'front_end_eager_ms': t_eager * 1e3, 'classifier_ms': t_clf * 1e3, 'utterances_per_s': batch / (t_fe + t_clf),
             'front_end_utterances_per_s': batch / t_fe, 'logits_shape': list(logits.shape),
             'accuracy': 'unpinned: the reference ships neither data nor weights'}
 
@@ -274,7 +287,8 @@ def other_paths(dev):
     del share_out
     # --- the opt-in matrix-pipe kernel (csrc/kernels_mfma512.h) on the metric's workload, for the record: one launch
     #     = the whole step; same algorithmic bytes as the step's fused kernel ---
-    if lib.dsp_plan_has_mfma512(plan.plan.handle) == 1:
+    has_m = lib.dsp_plan_has_mfma512(plan.plan.handle)
+    if has_m & 3:
         lay1 = plan.layout(np.empty((B, N), dtype=np.float32))
         g = torch.Generator(device=dev).manual_seed(3)
         w1 = [0.25 * torch.randn((B, N), device=dev, generator=g) for _ in range(4)]
@@ -284,18 +298,23 @@ def other_paths(dev):
         def one():
             k[0] += 1
             plan.run_raw(w1[k[0] % 4].data_ptr(), nat.WAVE_F32, lay1, o1.data_ptr(), DELTA_N, st)
-        nat.check(lib.dsp_debug_use_mfma512(1))
-        try:
-            us = timed(one, reps=100)
-        finally:
-            nat.check(lib.dsp_debug_use_mfma512(-1))
         byt = 4.0 * B * N + 4.0 * lay1.total_frames * 3 * CFG['numcep']
-        out['mfma512_kernel'] = {
-            'kernel': 'mfcc512m_kernel: DFT, mel and DCT as fp16 / bf16 (hi, lo) products on v_mfma_f32_16x16x32, opt-in '
-                      '(dsp_debug_use_mfma512); NOT the path `value` times',
-            'workload': f'{B} x 1 s, MFCC+delta+delta2 rows in one launch', 'us_per_launch': us,
-            'frames_per_s': lay1.total_frames / us * 1e6, 'algorithmic_GBps': byt / us / 1e3,
-            'frac_of_hbm_roofline': byt / us / 1e3 / HBM_PEAK_GBPS}
+        for mode, key, what in ((1, 'mfma512_kernel', 'mfcc512m_kernel (kernels_mfma512.h): 16 frames per product, per-column stage-1 matrices in LDS'),
+                                (2, 'mfma512t_kernel', 'mfcc512t_kernel (kernels_mfma512t.h): one frame per product, one register-resident '
+                                                       'matrix per DFT stage, window and twiddle on the vector pipe')):
+            if not (has_m >> (mode - 1)) & 1:
+                continue
+            nat.check(lib.dsp_debug_use_mfma512(mode))
+            try:
+                us = timed(one, reps=100)
+            finally:
+                nat.check(lib.dsp_debug_use_mfma512(-1))
+            out[key] = {
+                'kernel': what + ': DFT, mel and DCT as fp16 / bf16 (hi, lo) products on v_mfma_f32_16x16x32, opt-in '
+                                 f'(dsp_debug_use_mfma512({mode})); NOT the path `value` times',
+                'workload': f'{B} x 1 s, MFCC+delta+delta2 rows in one launch', 'us_per_launch': us,
+                'frames_per_s': lay1.total_frames / us * 1e6, 'algorithmic_GBps': byt / us / 1e3,
+                'frac_of_hbm_roofline': byt / us / 1e3 / HBM_PEAK_GBPS}
         del w1, o1
     return out
 

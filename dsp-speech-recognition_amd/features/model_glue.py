@@ -128,6 +128,17 @@ def model_finalize(mfcc0, frame_offsets, delta_n=3, max_len=200):
     return d_out.download((max_len, B, 3 * C), np.float32), d_len.download((B,), np.int32)
 
 
+class _ModelFeatureGraph:
+    """What ModelFeatureBatch.capture returns: replay() re-runs the captured launches on whatever ``waves`` holds now."""
+
+    def __init__(self, graph, waves, m0, inp, len0, layout):
+        self.graph, self.waves, self.m0, self.inp, self.len0, self.layout = graph, waves, m0, inp, len0, layout
+
+    def replay(self):
+        self.graph.replay()
+        return self.inp, self.len0
+
+
 class ModelFeatureBatch:
     """Batched, device-resident form of RNNModel.get_batch_full (model.py:113-135): endpointing ->
     (optional endpoint jitter, model.py:54-60) -> trim -> unit variance -> MFCC on the (1, N) view (no
@@ -198,6 +209,46 @@ class ModelFeatureBatch:
         if extra:
             inp = torch.cat([inp] + extra, dim=2)
         return inp, len0.cpu().numpy(), seg
+
+    def enqueue(self, d_wave, wave_dtype, lay, d_m0, d_inp, d_len0, stream):
+        """The default call (no optional streams, no jitter) as launches only -- raw device pointers, nothing allocated,
+        nothing synchronised: endpointing, the layout glue, the feature kernel on the clips in place and the finalize
+        kernel.  ``d_m0``: [lay.frames_bound, C] fp32 scratch, ``d_inp``: [max_len, B, 3 C] fp32, ``d_len0``: [B] int32."""
+        from . import _native as nat
+        from .batch import _stream_ptr
+        lib = nat.load()
+        st = _stream_ptr(stream)
+        C = self.pipe.features.C
+        self.pipe.launch(d_wave, wave_dtype, lay, d_m0, stream, None, defer_c0_shift=True)
+        if lay.c0_shift_pending:
+            nat.check(lib.dsp_model_finalize_segments_batch(d_m0, C, lay.d_frame_off.ptr, lay.d_seg.ptr, lay.d_work.ptr, lay.n_utt, C,
+                                                            self.delta_n, self.max_len, d_inp, d_len0, st))
+        else:
+            nat.check(lib.dsp_model_finalize_batch(d_m0, C, lay.d_frame_off.ptr, lay.n_utt, C, self.delta_n, self.max_len,
+                                                   d_inp, d_len0, st))
+
+    def capture(self, waves, layout):
+        """A HIP graph of ``enqueue`` over device-resident ``waves`` (torch tensor, int16 / float32) and a prepared layout:
+        ``g = mfb.capture(waves, lay)``; put new clips of the same lengths into ``waves`` and call ``g.replay()`` ->
+        (inp [max_len, B, 39], len0 [B] int32), both on the device, valid after the current stream's work (no host
+        synchronisation).  One eager call runs first (it builds the layout's long-lived index tables)."""
+        import torch
+        from .batch import _wave_dtype_of
+        dev = waves.device
+        C, B = self.pipe.features.C, layout.n_utt
+        m0 = torch.empty((max(layout.frames_bound, 1), C), dtype=torch.float32, device=dev)
+        inp = torch.empty((self.max_len, B, 3 * C), dtype=torch.float32, device=dev)
+        len0 = torch.empty(B, dtype=torch.int32, device=dev)
+        dtype = _wave_dtype_of(waves)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            self.enqueue(waves.data_ptr(), dtype, layout, m0.data_ptr(), inp.data_ptr(), len0.data_ptr(), side)
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            self.enqueue(waves.data_ptr(), dtype, layout, m0.data_ptr(), inp.data_ptr(), len0.data_ptr(), torch.cuda.current_stream(dev))
+        return _ModelFeatureGraph(graph, waves, m0, inp, len0, layout)
 
     def _timefeat_streams(self, lay, st, dev):
         """[max_len, B, 2]: z-scored frame amplitude of the trimmed, scaled clips and its first difference

@@ -438,3 +438,28 @@ def test_model_feature_batch_reads_the_clips_in_place(rate):
         (m0, m1, m2), n = dsp_oracle.model_pipeline(clips[b], rate)
         ref = np.concatenate([m0, m1, m2], axis=1)[:200]
         assert len0[b] == min(n, 200) and normwise(got[:len(ref), b], ref) <= 1e-4, (b, normwise(got[:len(ref), b], ref))
+
+
+def test_model_feature_graph_replays_on_new_data():
+    """ModelFeatureBatch.capture: the default call as a HIP graph over pre-allocated buffers -- a replay on new clips of
+    the same lengths equals the eager call on them (endpoints are data dependent: the captured launches re-derive them)."""
+    import torch
+    from features.model_glue import ModelFeatureBatch
+    from golden_cases import make_signal
+    rate = 44100
+    clips_a = [make_signal(('vad', 500 + i, 60000 + 5000 * i, rate, 0.6)) for i in range(4)]
+    clips_b = [make_signal(('vad', 600 + i, 60000 + 5000 * i, rate, 0.45)) for i in range(4)]
+    so = np.concatenate(([0], np.cumsum([len(c) for c in clips_a]))).astype(np.int64)
+    buf = torch.from_numpy(np.concatenate(clips_a)).cuda()
+    mfb = ModelFeatureBatch(rate=rate)
+    lay = mfb.pipe.prepare(so, delta_n=0)
+    g = mfb.capture(buf, lay)
+    inp, len0 = g.replay()
+    torch.cuda.synchronize()
+    eager, elen, _ = ModelFeatureBatch(rate=rate).run(torch.from_numpy(np.concatenate(clips_a)).cuda(), so)
+    assert torch.equal(inp, eager) and np.array_equal(len0.cpu().numpy(), elen)
+    buf.copy_(torch.from_numpy(np.concatenate(clips_b)).cuda())
+    inp, len0 = g.replay()
+    torch.cuda.synchronize()
+    eager, elen, _ = ModelFeatureBatch(rate=rate).run(torch.from_numpy(np.concatenate(clips_b)).cuda(), so)
+    assert torch.equal(inp, eager) and np.array_equal(len0.cpu().numpy(), elen)
