@@ -49,7 +49,7 @@ NOMINAL_GHZ = 2.4
 
 def compute_roof(kernel_ms):
     lane_ops, clock, src = None, None, None
-    for name in ('r3_instr.json', 'r2_instr.json'):
+    for name in ('r4_instr.json', 'r3_instr.json', 'r2_instr.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as fh:
                 ij = json.load(fh)
@@ -596,7 +596,7 @@ def main():
 
     # HBM traffic per launch measured with rocprofv3 PMC passes (cannot be collected inside this process)
     traffic, step_traffic, traffic_source = None, None, None
-    for name in ('r3_traffic.json',):     # FETCH / WRITE passes of THIS kernel (the fused one); older files describe the round-2 kernel
+    for name in ('r4_traffic.json', 'r3_traffic.json'):     # FETCH / WRITE passes of THIS kernel (the fused one); older files describe the round-2 kernel
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as fh:
                 tj = json.load(fh)
