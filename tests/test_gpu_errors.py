@@ -88,7 +88,8 @@ def test_round3_entry_points_reject_bad_arguments(env):
     assert lib.dsp_mfcc_delta_segments_batch(*args, work.ptr, 64, res.ptr, None) == -1      # work buffer too small
     assert 'work buffer' in _msg(lib)
     assert lib.dsp_mfcc_delta_segments_batch(*args, None, int(nbytes.value), res.ptr, None) == -1
-    assert lib.dsp_mfcc_delta_segments_batch(*args[:8], 0, 1, work.ptr, int(nbytes.value), res.ptr, None) == -1   # delta N < 1
+    assert lib.dsp_mfcc_delta_segments_batch(*args[:8], -1, 1, work.ptr, int(nbytes.value), res.ptr, None) == -1   # delta N < 0 (0 = cepstra only, round 4)
+    assert lib.dsp_mfcc_delta_segments_batch(*args[:8], 0, 1, work.ptr, int(nbytes.value), res.ptr, None) == 0
     assert lib.dsp_mfcc_delta_segments_batch(*args, work.ptr, int(nbytes.value), res.ptr, None) == 0
     assert lib.dsp_pitch_track_batch(None, d_fo.ptr, 2, 180, 20, 2, amp.ptr, None) == -1
     assert lib.dsp_pitch_track_batch(x.ptr, d_fo.ptr, 2, 300, 20, 2, amp.ptr, None) == -1
