@@ -415,6 +415,190 @@ __global__ __launch_bounds__(64 * VAD_WAVES) void vad_sum_kernel(VadParams P, Ba
     }
 }
 
+// int16 input, sum |x|, vector-aligned frames -- the endpoint path's standard case (16-bit wav data, get_amplitude and
+// get_zcr of endpoint.py:109-126, 182-198) -- in integer arithmetic on packed halves, a third of vad_sum_kernel's
+// vector instructions (it was issue bound: 811 vector instructions per group of 16 frames, 18 us per 49 MB):
+//   * per 4-sample vector (two dwords w0 = x1:x0, w1 = x3:x2): sgn = clamp(x, -1, 1) on both halves (v_pk_min / max_i16),
+//     |x0| + .. + |x3| = two v_dot2_i32_i16 of (x, sgn); the sign changes of the pairs (x[i-1], x[i]) are the halves
+//     equal to -1 of sgn x (sgn shifted by one sample: v_alignbit over the previous dword, the previous LANE's last
+//     dword through DPP), counted with one v_perm / v_and / v_bcnt.  Exact: nothing is rounded anywhere.
+//   * both numbers go to LDS in the vectors' own order; every lane then takes 12 CONSECUTIVE vectors (three
+//     conflict-free ds_read_b128 per array: a lane stride of 12 dwords spreads 16 lanes over all 64 banks), forms their
+//     running sums, the wave scans the 64 lane totals with DPP, and the prefix sums go back in place.
+//   * frame f = vectors [f S/4, f S/4 + L/4): two prefix differences per frame instead of a walk over L/4 vectors; its
+//     count drops the pair in front of its first sample, re-read from memory by the frame's lane at the group's start.
+#define VAD_SCAN_CH 12     // vectors per lane in the prefix phase: 64 x 12 = 64 x VAD_NSTAGE
+typedef short vad_s2 __attribute__((ext_vector_type(2)));
+typedef int vad_i4 __attribute__((ext_vector_type(4)));
+typedef unsigned int vad_u2u __attribute__((ext_vector_type(2), aligned(2)));
+
+// clamp(x, -1, 1) on both halves (hipcc expands __builtin_elementwise_min / max on short2 into compares and selects)
+__device__ __forceinline__ vad_s2 vad_sgn2(vad_s2 x) {
+    uint32_t t;
+    asm("v_pk_min_i16 %0, %1, %2\n\tv_pk_max_i16 %0, %0, %3" : "=&v"(t) : "v"(__builtin_bit_cast(uint32_t, x)), "s"(0x00010001u), "s"(0xffffffffu));
+    return __builtin_bit_cast(vad_s2, t);
+}
+
+template <int FR, bool RAGGED>
+__global__ __launch_bounds__(64 * VAD_WAVES) void vad_scan_kernel(VadParams P, BatchGeom bg,
+                                                                  const int16_t* __restrict__ wave,
+                                                                  double* __restrict__ amp_sum,
+                                                                  int32_t* __restrict__ zcr) {
+    constexpr int SHIFT = FR == 16 ? 4 : 2;
+    static_assert(VAD_SCAN_CH * 64 >= VAD_NSTAGE * 64, "the prefix phase covers every staged vector");
+    extern __shared__ __attribute__((aligned(256))) float smem_f[];
+    const int tid = threadIdx.x;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    int32_t* pa = reinterpret_cast<int32_t*>(smem_f) + wid * (2 * 64 * VAD_SCAN_CH);   // |x| sums per vector, then their prefix sums
+    int32_t* pe = pa + 64 * VAD_SCAN_CH;                                               // sign changes, likewise
+    const int total_groups = RAGGED ? P.group_off[bg.n_utt] : (int)P.total_groups;
+    const int gstride = (int)gridDim.x * VAD_WAVES;
+    const int vpf = P.L >> 2, vps = P.S >> 2;      // vectors per frame / per hop
+    const int nr = (P.span_vec + 63) >> 6;          // rounds of 64 vectors (<= VAD_NSTAGE)
+
+    // Where a group lives (two levels of dependent scalar loads for ragged batches).  Issuing the NEXT group's behind this
+    // group's sample loads was measured and lost 1.4 us per 49 MB launch: the wait for them lands in front of the arithmetic.
+    struct Loc { int t0, T, nsamp; int64_t s0, row0; };
+    auto locate = [&](int G) -> Loc {
+        Loc g;
+        if constexpr (RAGGED) {
+            const int utt = P.group_utt[G];
+            g.t0 = (G - P.group_off[utt]) << SHIFT;
+            g.s0 = bg.sample_off[utt];
+            g.nsamp = (int)(bg.sample_off[utt + 1] - g.s0);
+            g.row0 = bg.frame_off[utt];
+            g.T = (int)(bg.frame_off[utt + 1] - g.row0);
+        } else {
+            const int gpu = (int)P.groups_per_utt;
+            const int utt = G / gpu;
+            g.t0 = (G - utt * gpu) << SHIFT;
+            g.nsamp = (int)bg.uniform_samples;
+            g.T = (int)bg.uniform_frames;
+            g.s0 = (int64_t)utt * bg.uniform_samples;
+            g.row0 = (int64_t)utt * bg.uniform_frames;
+        }
+        return g;
+    };
+    int G = __builtin_amdgcn_readfirstlane((int)blockIdx.x * VAD_WAVES + wid);
+    if (G >= total_groups) return;
+    Loc cur = locate(G);
+    for (;;) {
+        const int t0 = cur.t0, T = cur.T, nsamp = cur.nsamp;
+        const int64_t s0 = cur.s0, row0 = cur.row0;
+        const int base = t0 * P.S;
+        const int16_t* gp = wave + s0 + base;
+        // the pair in front of the first sample of frame `lane` (frame 0 of a group: its vector is staged with a zero in
+        // front); idle lanes read the group's first sample twice.  Used in the frame phase, so nothing waits for it here.
+        const bool b0_lane = lane > 0 && lane < FR && base + lane * P.S < nsamp;
+        const int b0_xm = gp[b0_lane ? lane * P.S - 1 : 0], b0_x0 = gp[b0_lane ? lane * P.S : 0];
+        // ---- all loads first, no branch on a lane's position: a vector that crosses the clip's end is read as the clip's
+        //      LAST four samples and shifted down, zeros above (clips shorter than 4 samples: element by element) ----
+        uint2 raw[VAD_NSTAGE];
+        if (nsamp >= 4) {
+            const int16_t* const tailp = gp + (nsamp - base - 4);
+#pragma unroll
+            for (int r = 0; r < VAD_NSTAGE; ++r)
+                if (r < nr) {
+                    const int16_t* vp = gp + 4 * (lane + 64 * r);
+                    if (base + 256 * (r + 1) <= nsamp) {       // the whole round lies inside the clip (wave-uniform)
+                        const vad_u2u t = *reinterpret_cast<const vad_u2u*>(vp);
+                        raw[r] = make_uint2(t.x, t.y);
+                    } else if (base + 256 * r >= nsamp) {       // the whole round lies behind the clip's end
+                        raw[r] = make_uint2(0u, 0u);
+                    } else {                                    // the one round in between
+                        const int c = nsamp - (base + 4 * (lane + 64 * r));     // samples of this vector inside the clip
+                        const vad_u2u t = *reinterpret_cast<const vad_u2u*>(c >= 4 ? vp : tailp);
+                        raw[r] = make_uint2(t.x, t.y);                          // shifted into place below, once everything is on its way
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int r = 0; r < VAD_NSTAGE; ++r)
+                if (r < nr) {
+                    const int rel = base + 4 * (lane + 64 * r);
+                    uint32_t e[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) e[k] = rel + k < nsamp ? (uint32_t)(uint16_t)gp[4 * (lane + 64 * r) + k] : 0u;
+                    raw[r] = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
+                }
+        }
+        if (nsamp >= 4 && base + 256 * nr > nsamp) {    // the group reaches the clip's end (wave-uniform)
+#pragma unroll
+            for (int r = 0; r < VAD_NSTAGE; ++r)
+                if (r < nr && base + 256 * (r + 1) > nsamp && base + 256 * r < nsamp) {
+                    const int c = nsamp - (base + 4 * (lane + 64 * r));
+                    const uint64_t q = ((uint64_t)raw[r].y << 32) | raw[r].x;
+                    const uint64_t qs = c >= 4 ? q : (c <= 0 ? 0ull : q >> (16 * (4 - c)));
+                    raw[r] = make_uint2((uint32_t)qs, (uint32_t)(qs >> 32));
+                }
+        }
+        int left = 0;   // sgn of the two samples in front of lane 0's vector (the first staged sample has nothing in front)
+#pragma unroll
+        for (int r = 0; r < VAD_NSTAGE; ++r)
+            if (r < nr) {
+                const vad_s2 x0 = __builtin_bit_cast(vad_s2, raw[r].x), x1 = __builtin_bit_cast(vad_s2, raw[r].y);
+                const vad_s2 g0 = vad_sgn2(x0), g1 = vad_sgn2(x1);
+                const int g1i = __builtin_bit_cast(int, g1);
+                const int gprev = __builtin_amdgcn_update_dpp(left, g1i, 0x138, 0xF, 0xF, false);   // wave_shr:1, lane 0 keeps `left`
+                left = __builtin_amdgcn_readlane(g1i, 63);
+                int a = __builtin_amdgcn_sdot2(x0, g0, 0, false);
+                a = __builtin_amdgcn_sdot2(x1, g1, a, false);
+                const uint32_t g0u = __builtin_bit_cast(uint32_t, g0);
+                const vad_s2 t0v = __builtin_bit_cast(vad_s2, __builtin_amdgcn_alignbit(g0u, (uint32_t)gprev, 16));   // sgn x0 : sgn x[-1]
+                const vad_s2 t1v = __builtin_bit_cast(vad_s2, __builtin_amdgcn_alignbit((uint32_t)g1i, g0u, 16));      // sgn x2 : sgn x1
+                const vad_s2 p0 = g0 * t0v, p1 = g1 * t1v;                                                             // -1 where the pair changes sign
+                const uint32_t m = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, p0), __builtin_bit_cast(uint32_t, p1), 0x03010705u) & 0x80808080u;
+                pa[lane + 64 * r] = a;
+                pe[lane + 64 * r] = __builtin_popcount(m);
+            }
+        F512_FENCE();
+        // ---- prefix sums over the vectors: lane l owns vectors 12 l .. 12 l + 11 ----
+        {
+            vad_i4* qa = reinterpret_cast<vad_i4*>(pa + VAD_SCAN_CH * lane);
+            vad_i4* qe = reinterpret_cast<vad_i4*>(pe + VAD_SCAN_CH * lane);
+            int va[VAD_SCAN_CH], ve[VAD_SCAN_CH];
+#pragma unroll
+            for (int k = 0; k < VAD_SCAN_CH / 4; ++k) {
+                const vad_i4 x = qa[k], y = qe[k];
+                va[4 * k] = x.x; va[4 * k + 1] = x.y; va[4 * k + 2] = x.z; va[4 * k + 3] = x.w;
+                ve[4 * k] = y.x; ve[4 * k + 1] = y.y; ve[4 * k + 2] = y.z; ve[4 * k + 3] = y.w;
+            }
+#pragma unroll
+            for (int k = 1; k < VAD_SCAN_CH; ++k) { va[k] += va[k - 1]; ve[k] += ve[k - 1]; }
+            const int oa = dsp_wave_scan_i32(va[VAD_SCAN_CH - 1]) - va[VAD_SCAN_CH - 1];   // sum of the lanes in front
+            const int oe = dsp_wave_scan_i32(ve[VAD_SCAN_CH - 1]) - ve[VAD_SCAN_CH - 1];
+#pragma unroll
+            for (int k = 0; k < VAD_SCAN_CH / 4; ++k) {
+                vad_i4 x, y;
+                x.x = va[4 * k] + oa; x.y = va[4 * k + 1] + oa; x.z = va[4 * k + 2] + oa; x.w = va[4 * k + 3] + oa;
+                y.x = ve[4 * k] + oe; y.y = ve[4 * k + 1] + oe; y.z = ve[4 * k + 2] + oe; y.w = ve[4 * k + 3] + oe;
+                qa[k] = x;
+                qe[k] = y;
+            }
+        }
+        F512_FENCE();
+        // ---- frame f = vectors [f vps, f vps + vpf) ----
+        if (lane < FR) {
+            const int lo = lane * vps, hi = lo + vpf;
+            int sa = pa[hi - 1], se = pe[hi - 1];
+            if (lo > 0) {
+                sa -= pa[lo - 1];
+                se -= pe[lo - 1];
+            }
+            const int t = t0 + lane;
+            if (t < T) {
+                amp_sum[row0 + t] = (double)sa;
+                zcr[row0 + t] = se - ((b0_lane && b0_xm * b0_x0 < 0) ? 1 : 0);
+            }
+        }
+        F512_FENCE();
+        G += gstride;
+        if (G >= total_groups) break;
+        cur = locate(G);
+    }
+}
+
 // Picks the tile shape; returns 0 if the configuration has to take the one-wave-per-frame kernel.
 static inline int vad_tile_frames(int32_t L, int32_t S) {
     if (L < 64 || S < 1) return 0;
@@ -455,6 +639,18 @@ static int vad_tile_launch_k(const VadParams& P, const BatchGeom& bg, const void
         const size_t sum_bytes = f32_exact ? 4 : 8;
         Q.off_e = (int32_t)((((size_t)Q.span_vec * sum_bytes + 15) / 16 * 16) / 4);       // floats
         Q.wave_floats = (int32_t)(((size_t)Q.off_e + Q.span_vec + 63) / 64 * 64);
+        static const bool no_scan = getenv("DSP_VAD_NOSCAN") != nullptr;   // A/B aid: keep vad_sum_kernel for int16 input
+        if constexpr (DTYPE == DSP_WAVE_I16) {
+            // int16, sum |x|: integer partials and prefix sums (a vector's sum stays below 2^17, a group's below 2^27)
+            if (f32_exact && !no_scan && Q.span_vec <= 64 * VAD_NSTAGE && P.L >= 4) {
+                const size_t ldss = (size_t)VAD_WAVES * 2 * 64 * VAD_SCAN_CH * sizeof(int32_t);
+                int64_t blockss = (groups_bound + VAD_WAVES - 1) / VAD_WAVES;
+                const int64_t caps = (int64_t)dsp_cu_count() * 6;          // 24.6 KB per workgroup: six per CU
+                if (blockss > caps) blockss = caps;
+                vad_scan_kernel<FR, RAGGED><<<(int)blockss, 64 * VAD_WAVES, ldss, st>>>(Q, bg, static_cast<const int16_t*>(d_wave), d_amp, d_zcr);
+                return hipGetLastError() == hipSuccess ? DSP_OK : DSP_EHIP;
+            }
+        }
         if (Q.span_vec <= 64 * VAD_NSTAGE) {
             const size_t lds3 = (size_t)VAD_WAVES * Q.wave_floats * sizeof(float);
             int64_t blocks3 = (groups_bound + VAD_WAVES - 1) / VAD_WAVES;

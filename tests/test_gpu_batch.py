@@ -304,6 +304,30 @@ def test_vad_tile_kernel_vs_per_frame_kernel_and_oracle(rate, dtype):
         assert list(tile[1][fo_r[b]:fo_r[b + 1]]) == list(dsp_oracle.get_zcr(frames))
 
 
+@pytest.mark.parametrize('rate', [16000, 48000, 8000])
+def test_vad_int16_extreme_values_are_exact(rate):
+    """The integer amplitude / zero-crossing kernel (vad_scan_kernel) at the ends of the int16 range: every sample
+    -32768 (the largest per-vector sum, no crossing), +32767 / -32768 alternating (a crossing at every pair), runs of
+    zeros between opposite signs (never a crossing), ragged lengths and odd sample offsets.  Every value exact."""
+    from features.batch import EndpointPlan
+    ep = EndpointPlan(rate, 0.03, 0.01)
+    rng = np.random.default_rng(5)
+    n = 2 * rate + 6
+    clips = [np.full(n, -32768, dtype=np.int16),
+             np.where(np.arange(n) % 2 == 0, 32767, -32768).astype(np.int16),
+             np.where(np.arange(n) % 3 == 0, 0, np.where(np.arange(n) % 2 == 0, 1, -1)).astype(np.int16),
+             rng.integers(-32768, 32768, n // 2 + 1).astype(np.int16),
+             rng.integers(-2, 3, ep.L + 3 * ep.S + 1).astype(np.int16),
+             np.array([5], dtype=np.int16)]
+    so = np.concatenate([[0], np.cumsum([len(c) for c in clips])]).astype(np.int64)
+    _, amp, zcr, fo = ep.detect_batch(np.concatenate(clips), sample_offsets=so, return_feature=True)
+    for b, c in enumerate(clips):
+        frames = dsp_oracle.to_frames(c.astype(np.float64), rate, t=0.03, step=0.01)
+        assert fo[b + 1] - fo[b] == frames.shape[0]
+        assert np.array_equal(amp[fo[b]:fo[b + 1]], dsp_oracle.get_amplitude(frames)), b
+        assert list(zcr[fo[b]:fo[b + 1]]) == list(dsp_oracle.get_zcr(frames)), b
+
+
 @pytest.mark.parametrize('copy_trimmed', [False, True], ids=['in_place', 'trimmed_copy'])
 @pytest.mark.parametrize('unit_variance', [False, True])
 def test_config4_vad_trim_mfcc_pipeline(unit_variance, copy_trimmed):
