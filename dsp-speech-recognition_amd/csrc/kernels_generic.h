@@ -340,6 +340,7 @@ __global__ __launch_bounds__(256) void delta_rows_kernel(const float* __restrict
     const int D = DC > 0 ? DC : D_rt;
     int64_t base;
     int T, tile;
+    int32_t utt_ = 0;
     if (threadIdx.x == 0) s_shift = 0.f;
     if (bg.uniform_frames > 0) {
         const int u = (int)blockIdx.x / tiles_per_utt_uniform;
@@ -357,14 +358,14 @@ __global__ __launch_bounds__(256) void delta_rows_kernel(const float* __restrict
         // clip.  Dividing the clip by its standard deviation sd scales every power by 1 / sd^2, i.e. adds -ln sd^2 to
         // every log: the cepstra k >= 1 do not move (their DCT rows sum to zero), c0 = log(energy) loses ln(var) --
         // unless the frame's energy was exactly zero (then it is ln(eps) either way, base.py:26).  model.py:62-63.
-        if (stats != nullptr && threadIdx.x == 0) {
-            const double n = (double)(seg[2 * u + 1] - seg[2 * u]);
-            if (n > 0.0) {
-                const double mean = stats[2 * u] / n;
-                const double var = stats[2 * u + 1] / n - mean * mean;
-                s_shift = var > 0.0 ? (float)log(var) : 0.f;       // zero variance: sklearn scales by 1
-            }
-        }
+        utt_ = u;
+    }
+    // the statistics: loaded here, next to the tile's own loads, turned into the shift (a logarithm) behind them
+    double st_n = 0.0, st_s = 0.0, st_q = 0.0;
+    if (stats != nullptr && threadIdx.x == 0) {
+        st_n = (double)(seg[2 * utt_ + 1] - seg[2 * utt_]);
+        st_s = stats[2 * utt_];
+        st_q = stats[2 * utt_ + 1];
     }
     const int t0 = tile * DT_TILE;
     const int nt = (T - t0) < DT_TILE ? (T - t0) : DT_TILE;
@@ -388,6 +389,11 @@ __global__ __launch_bounds__(256) void delta_rows_kernel(const float* __restrict
 #pragma unroll
         for (int k = 0; k < 8; ++k)
             if (i0 + 256 * k < rows_x * D) sx[i0 + 256 * k] = v[k];
+    }
+    if (stats != nullptr && threadIdx.x == 0 && st_n > 0.0) {
+        const double mean = st_s / st_n;
+        const double var = st_q / st_n - mean * mean;
+        s_shift = var > 0.0 ? (float)log(var) : 0.f;       // zero variance: sklearn scales by 1
     }
     __syncthreads();
     if (stats != nullptr) {
