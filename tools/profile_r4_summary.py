@@ -20,7 +20,7 @@ def short(name):
         fd = args[7] if len(args) > 7 else '0'      # <NROWS, NI, CAPS, NSTAGE, DTYPE, WAVES, RAGGED, FD>
         ragged = len(args) > 6 and args[6] in ('true', '1')
         return 'mfcc512_fused' if fd not in ('0', 'false') else ('mfcc512_ragged' if ragged else 'mfcc512_kernel')
-    for key in ('mfcc1536_kernel', 'delta_rows_kernel', 'delta_tiled_kernel', 'vad_sum_kernel',
+    for key in ('mfcc1536_kernel', 'delta_rows_kernel', 'delta_tiled_kernel', 'vad_sum_kernel', 'vad_scan_kernel',
                 'vad_vec_kernel', 'endpoint_rule_kernel', 'endpoint_layout_kernel', 'trim_scale_kernel',
                 'f512_group_prefix_kernel', 'features_generic_kernel', 'prefix_ceil_kernel'):
         if key in name:
