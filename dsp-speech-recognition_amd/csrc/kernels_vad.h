@@ -415,9 +415,11 @@ __global__ __launch_bounds__(64 * VAD_WAVES) void vad_sum_kernel(VadParams P, Ba
     }
 }
 
-// int16 input, sum |x|, vector-aligned frames -- the endpoint path's standard case (16-bit wav data, get_amplitude and
-// get_zcr of endpoint.py:109-126, 182-198) -- in integer arithmetic on packed halves, a third of vad_sum_kernel's
-// vector instructions (it was issue bound: 811 vector instructions per group of 16 frames, 18 us per 49 MB):
+// int16 input, sum |x|, ANY frame length and hop -- the endpoint path's standard case (16-bit wav data, get_amplitude and
+// get_zcr of endpoint.py:109-126, 182-198; 30 ms / 10 ms frames are 480 / 160 samples at 16 kHz, 1323 / 441 at 44.1 kHz)
+// -- in integer arithmetic on packed halves, a third of vad_sum_kernel's vector instructions (it was issue bound: 811
+// vector instructions per group of 16 frames, 18 us per 49 MB; vad_vec_kernel, which served the frames that are not
+// whole vectors, 54 us per 69 MB):
 //   * per 4-sample vector (two dwords w0 = x1:x0, w1 = x3:x2): sgn = clamp(x, -1, 1) on both halves (v_pk_min / max_i16),
 //     |x0| + .. + |x3| = two v_dot2_i32_i16 of (x, sgn); the sign changes of the pairs (x[i-1], x[i]) are the halves
 //     equal to -1 of sgn x (sgn shifted by one sample: v_alignbit over the previous dword, the previous LANE's last
@@ -425,8 +427,10 @@ __global__ __launch_bounds__(64 * VAD_WAVES) void vad_sum_kernel(VadParams P, Ba
 //   * both numbers go to LDS in the vectors' own order; every lane then takes 12 CONSECUTIVE vectors (three
 //     conflict-free ds_read_b128 per array: a lane stride of 12 dwords spreads 16 lanes over all 64 banks), forms their
 //     running sums, the wave scans the 64 lane totals with DPP, and the prefix sums go back in place.
-//   * frame f = vectors [f S/4, f S/4 + L/4): two prefix differences per frame instead of a walk over L/4 vectors; its
-//     count drops the pair in front of its first sample, re-read from memory by the frame's lane at the group's start.
+//   * frame f = samples [f S, f S + L) of the group = a run of whole vectors, two prefix differences instead of a walk
+//     over L/4 vectors, plus at most three samples in front and three behind, which the frame's lane reads from memory
+//     itself at the group's start (with the sample in front of each run, for the pairs); a frame that starts on a vector
+//     drops that vector's first pair.
 #define VAD_SCAN_CH 12     // vectors per lane in the prefix phase: 64 x 12 = 64 x VAD_NSTAGE
 typedef short vad_s2 __attribute__((ext_vector_type(2)));
 typedef int vad_i4 __attribute__((ext_vector_type(4)));
@@ -454,7 +458,6 @@ __global__ __launch_bounds__(64 * VAD_WAVES) void vad_scan_kernel(VadParams P, B
     int32_t* pe = pa + 64 * VAD_SCAN_CH;                                               // sign changes, likewise
     const int total_groups = RAGGED ? P.group_off[bg.n_utt] : (int)P.total_groups;
     const int gstride = (int)gridDim.x * VAD_WAVES;
-    const int vpf = P.L >> 2, vps = P.S >> 2;      // vectors per frame / per hop
     const int nr = (P.span_vec + 63) >> 6;          // rounds of 64 vectors (<= VAD_NSTAGE)
 
     // Where a group lives (two levels of dependent scalar loads for ragged batches).  Issuing the NEXT group's behind this
@@ -488,10 +491,22 @@ __global__ __launch_bounds__(64 * VAD_WAVES) void vad_scan_kernel(VadParams P, B
         const int64_t s0 = cur.s0, row0 = cur.row0;
         const int base = t0 * P.S;
         const int16_t* gp = wave + s0 + base;
-        // the pair in front of the first sample of frame `lane` (frame 0 of a group: its vector is staged with a zero in
-        // front); idle lanes read the group's first sample twice.  Used in the frame phase, so nothing waits for it here.
-        const bool b0_lane = lane > 0 && lane < FR && base + lane * P.S < nsamp;
-        const int b0_xm = gp[b0_lane ? lane * P.S - 1 : 0], b0_x0 = gp[b0_lane ? lane * P.S : 0];
+        // Frame `lane` = samples [flo, fhi) of the group = the whole vectors [vlo, vhi) plus up to three samples in front
+        // and three behind (none when L and S are multiples of 4).  The lane reads those few, and the sample in front of
+        // each run, itself: x[flo - 1 .. flo + 2] and x[4 vhi - 1 .. 4 vhi + 2], zeros outside the clip (idle lanes read
+        // the group's first sample).  Used in the frame phase, so nothing waits for them here.
+        const int flo = lane * P.S, fhi = flo + P.L;
+        const int vlo = (flo + 3) >> 2, vhi = fhi >> 2;
+        int hw[4], tw[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ih = flo - 1 + k, it = 4 * vhi - 1 + k;
+            const bool okh = lane < FR && ih >= 0 && base + ih < nsamp, okt = lane < FR && base + it < nsamp;
+            hw[k] = gp[okh ? ih : 0];
+            tw[k] = gp[okt ? it : 0];
+            hw[k] = okh ? hw[k] : 0;
+            tw[k] = okt ? tw[k] : 0;
+        }
         // ---- all loads first, no branch on a lane's position: a vector that crosses the clip's end is read as the clip's
         //      LAST four samples and shifted down, zeros above (clips shorter than 4 samples: element by element) ----
         uint2 raw[VAD_NSTAGE];
@@ -578,18 +593,33 @@ __global__ __launch_bounds__(64 * VAD_WAVES) void vad_scan_kernel(VadParams P, B
             }
         }
         F512_FENCE();
-        // ---- frame f = vectors [f vps, f vps + vpf) ----
+        // ---- frame f: two prefix differences over its whole vectors, the edge samples one by one ----
         if (lane < FR) {
-            const int lo = lane * vps, hi = lo + vpf;
-            int sa = pa[hi - 1], se = pe[hi - 1];
-            if (lo > 0) {
-                sa -= pa[lo - 1];
-                se -= pe[lo - 1];
+            int sa = pa[vhi - 1], se = pe[vhi - 1];
+            if (vlo > 0) {
+                sa -= pa[vlo - 1];
+                se -= pe[vlo - 1];
             }
+            const int hr = 4 * vlo - flo, tq = fhi - 4 * vhi;      // samples in front of / behind the whole vectors
+            auto cross = [](int a, int b) -> int { return a * b < 0 ? 1 : 0; };   // int16 x int16: exact
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (k < hr) {
+                    sa += abs(hw[1 + k]);                          // x[flo + k]
+                    if (k > 0) se += cross(hw[k], hw[1 + k]);      // pairs (i - 1, i), i = flo + 1 .. flo + hr - 1
+                }
+                if (k < tq) {
+                    sa += abs(tw[1 + k]);                          // x[4 vhi + k]
+                    se += cross(tw[k], tw[1 + k]);                 // pairs (i - 1, i), i = 4 vhi .. fhi - 1
+                }
+            }
+            // the first whole vector's count starts with the pair (4 vlo - 1, 4 vlo): outside the frame when the frame starts
+            // there (frame 0 of a group: that vector was staged with a zero in front, nothing to take back)
+            if (hr == 0 && lane > 0) se -= cross(hw[0], hw[1]);
             const int t = t0 + lane;
             if (t < T) {
                 amp_sum[row0 + t] = (double)sa;
-                zcr[row0 + t] = se - ((b0_lane && b0_xm * b0_x0 < 0) ? 1 : 0);
+                zcr[row0 + t] = se;
             }
         }
         F512_FENCE();
@@ -632,6 +662,21 @@ static int vad_tile_launch_k(const VadParams& P, const BatchGeom& bg, const void
     const bool f32_exact = DTYPE == DSP_WAVE_I16 && !P.use_sq && (P.L + 64 / FR - 1) / (64 / FR) < 512;
     static const bool force_walk = getenv("DSP_VAD_WALK") != nullptr;   // A/B aid: keep the per-frame walk
     static const bool no_sum = getenv("DSP_VAD_NOSUM") != nullptr;       // A/B aid: skip vad_sum_kernel
+    static const bool no_scan = getenv("DSP_VAD_NOSCAN") != nullptr;   // A/B aid: keep the round-3 kernels for int16 input
+    if constexpr (DTYPE == DSP_WAVE_I16) {
+        // int16, sum |x|, any frame length and hop: integer partials and prefix sums (a vector's sum stays below 2^17, a
+        // group's below 2^27)
+        VadParams Q = P;
+        Q.span_vec = ((FR - 1) * P.S + P.L + 3) / 4;
+        if (!P.use_sq && !no_scan && !force_walk && !no_sum && Q.span_vec <= 64 * VAD_NSTAGE && P.L >= 8) {
+            const size_t ldss = (size_t)VAD_WAVES * 2 * 64 * VAD_SCAN_CH * sizeof(int32_t);
+            int64_t blockss = (groups_bound + VAD_WAVES - 1) / VAD_WAVES;
+            const int64_t caps = (int64_t)dsp_cu_count() * 6;          // 24.6 KB per workgroup: six per CU
+            if (blockss > caps) blockss = caps;
+            vad_scan_kernel<FR, RAGGED><<<(int)blockss, 64 * VAD_WAVES, ldss, st>>>(Q, bg, static_cast<const int16_t*>(d_wave), d_amp, d_zcr);
+            return hipGetLastError() == hipSuccess ? DSP_OK : DSP_EHIP;
+        }
+    }
     if ((P.L % 4) == 0 && (P.S % 4) == 0 && !force_walk && !no_sum) {
         // vector-aligned frames: visit-once kernel with 8 (12) bytes of LDS per vector, both input types
         VadParams Q = P;
@@ -639,18 +684,6 @@ static int vad_tile_launch_k(const VadParams& P, const BatchGeom& bg, const void
         const size_t sum_bytes = f32_exact ? 4 : 8;
         Q.off_e = (int32_t)((((size_t)Q.span_vec * sum_bytes + 15) / 16 * 16) / 4);       // floats
         Q.wave_floats = (int32_t)(((size_t)Q.off_e + Q.span_vec + 63) / 64 * 64);
-        static const bool no_scan = getenv("DSP_VAD_NOSCAN") != nullptr;   // A/B aid: keep vad_sum_kernel for int16 input
-        if constexpr (DTYPE == DSP_WAVE_I16) {
-            // int16, sum |x|: integer partials and prefix sums (a vector's sum stays below 2^17, a group's below 2^27)
-            if (f32_exact && !no_scan && Q.span_vec <= 64 * VAD_NSTAGE && P.L >= 4) {
-                const size_t ldss = (size_t)VAD_WAVES * 2 * 64 * VAD_SCAN_CH * sizeof(int32_t);
-                int64_t blockss = (groups_bound + VAD_WAVES - 1) / VAD_WAVES;
-                const int64_t caps = (int64_t)dsp_cu_count() * 6;          // 24.6 KB per workgroup: six per CU
-                if (blockss > caps) blockss = caps;
-                vad_scan_kernel<FR, RAGGED><<<(int)blockss, 64 * VAD_WAVES, ldss, st>>>(Q, bg, static_cast<const int16_t*>(d_wave), d_amp, d_zcr);
-                return hipGetLastError() == hipSuccess ? DSP_OK : DSP_EHIP;
-            }
-        }
         if (Q.span_vec <= 64 * VAD_NSTAGE) {
             const size_t lds3 = (size_t)VAD_WAVES * Q.wave_floats * sizeof(float);
             int64_t blocks3 = (groups_bound + VAD_WAVES - 1) / VAD_WAVES;
