@@ -59,6 +59,39 @@ def test_device_features_feed_torch_rnn():
     assert np.array_equal(logits_gpu.argmax(1), logits_ref.argmax(1))
 
 
+@pytest.mark.parametrize('kind', ['hrnn', 'hrnn_att', 'transformer'])
+def test_device_features_feed_the_hierarchical_and_transformer_heads(kind):
+    """Row f-3 for the other classifiers the reference trains (rnn_clf.py:36-120, 166-203; restated in
+    features/classifier.py and pinned to the real classes by tests/test_classifier_golden.py): the [200, B, 39] tensor the
+    front end leaves on the device goes straight into them, and their (pre-dropout) logits equal those on the oracle's rows."""
+    import torch
+    from features import classifier as C
+    from features.batch import FeaturePlan
+    from features.model_glue import batch_to_rnn_input
+    dev = torch.device('cuda', 0)
+    rng = np.random.default_rng(22)
+    lens = [16000, 12000, 20000, 8000, 24000, 30000]
+    so = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+    flat = (0.25 * rng.standard_normal(so[-1])).astype(np.float32)
+    plan = FeaturePlan(winfunc=np.hamming, **CFG)
+    feats, fo = plan.mfcc_batch(torch.from_numpy(flat).to(dev), sample_offsets=so, delta_n=2)
+    inp, len0 = batch_to_rnn_input(feats, fo, 200)
+    assert inp.is_cuda
+    ref_inp = np.zeros((200, len(lens), 39), dtype=np.float32)
+    for b in range(len(lens)):
+        r = dsp_oracle.mfcc_delta(flat[so[b]:so[b + 1]].astype(np.float64), delta_n=2, winfunc=np.hamming, **CFG)
+        ref_inp[:min(len(r), 200), b] = r[:200]
+    torch.manual_seed(0)
+    head = {'hrnn': C.HRNNHead, 'hrnn_att': C.HRNNAttHead, 'transformer': C.TransformerHead}[kind]().eval()
+    C.fill_parameters(head, 77)
+    head = head.to(dev)
+    with torch.no_grad():
+        got = head(inp, np.asarray(len0), dropout=False)[0].cpu().numpy()
+        want = head(torch.from_numpy(ref_inp).to(dev), np.asarray(len0), dropout=False)[0].cpu().numpy()
+    assert got.shape == (len(lens), 20) and np.isfinite(got).all()
+    assert np.max(np.abs(got - want)) <= 1e-3 * max(1.0, float(np.max(np.abs(want))))
+
+
 M0_TOL = 1e-4   # measured 1.1e-5 (gpurun_out/parity_measured.json, round 2): the 1e-4 bar holds, no exception
 
 
