@@ -220,3 +220,19 @@ def test_scratch_slots_are_per_thread_and_never_shared():
     t.join()
     assert seen['buf'] is not b and not b.freed                           # another thread: its own slot
     assert Fake.live == 3
+
+
+def test_prologue_of_the_dense_nfft512_kernels_waits_for_exactly_its_table_loads():
+    """the prologue of mfcc512_kernel issues its table loads as inline asm (which the compiler's wait-count
+    insertion does not see) and waits for them with a hand-written s_waitcnt vmcnt(NSTAGE).  tools/asm_check_prologue.py
+    checks on the PRODUCT build's listing that exactly NSTAGE vector-memory instructions sit between them, on every path,
+    and that nothing touches the loads' destination registers before the wait -- for every dense instantiation."""
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not (shutil.which('hipcc') or os.path.exists('/opt/rocm/bin/hipcc')):
+        pytest.skip('no hipcc: the listing cannot be built here')
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'asm_check_prologue.py')], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert 'instantiations checked, 0 failed' in r.stdout
