@@ -658,16 +658,22 @@ __global__ __launch_bounds__(64 * WAVES, F512_MIN_WAVES_PER_SIMD) void mfcc512_k
         }
         if constexpr (RAGGED) {
             if (do_stats) {
-                // sums over each row of 16 lanes with DPP (vector pipe, no LDS traffic), then four lanes add to the
-                // utterance's accumulators
+                // sums over each row of 16 lanes with DPP (vector pipe, no LDS traffic)
                 float ws = st_s, wq = st_q;
                 ws += dpp_f32<0xB1>(ws);  wq += dpp_f32<0xB1>(wq);     // quad_perm [1,0,3,2]
                 ws += dpp_f32<0x4E>(ws);  wq += dpp_f32<0x4E>(wq);     // quad_perm [2,3,0,1]
                 ws += dpp_f32<0x141>(ws); wq += dpp_f32<0x141>(wq);    // row_half_mirror
                 ws += dpp_f32<0x140>(ws); wq += dpp_f32<0x140>(wq);    // row_mirror
-                if ((lane & 15) == 0) {
-                    unsafeAtomicAdd(bg.stats + 2 * utt, (double)ws);
-                    unsafeAtomicAdd(bg.stats + 2 * utt + 1, (double)wq);
+                // the four row sums meet in fp64 in scalar registers: ONE pair of atomics per group instead of four
+                double ds = 0.0, dq = 0.0;
+#pragma unroll
+                for (int rw = 0; rw < 64; rw += 16) {
+                    ds += (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ws), rw));
+                    dq += (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(wq), rw));
+                }
+                if (lane == 0) {
+                    unsafeAtomicAdd(bg.stats + 2 * utt, ds);
+                    unsafeAtomicAdd(bg.stats + 2 * utt + 1, dq);
                 }
             }
         }
