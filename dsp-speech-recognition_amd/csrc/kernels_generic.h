@@ -1047,6 +1047,7 @@ __global__ __launch_bounds__(256) void model_finalize_kernel(const float* __rest
     extern __shared__ __attribute__((aligned(16))) float fin_smem[];
     __shared__ double red[4];
     __shared__ double s_mu[32], s_inv[32];
+    __shared__ double s_part[256];
     __shared__ double s_shift;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int64_t base = frame_off[b];
@@ -1080,24 +1081,38 @@ __global__ __launch_bounds__(256) void model_finalize_kernel(const float* __rest
     __syncthreads();
     const double gmean = T > 0 ? (red[0] + red[1] + red[2] + red[3]) / ((double)T * (double)C) : 0.0;
     __syncthreads();
-    // per-coefficient mean and population std of x = mfcc - gmean (two passes, like numpy)
-    const int wid = tid >> 6, lane = tid & 63;
-    for (int c = wid; c < C; c += 4) {
+    // per-coefficient mean and population std of x = mfcc - gmean (two passes, like numpy).  All C coefficients at once:
+    // thread (c, j) sums every J-th frame of coefficient c, the J partial sums of a coefficient meet in LDS -- two short
+    // phases instead of ceil(C / 4) rounds of a wave per coefficient with two 64-lane fp64 butterflies each
+    {
+        const int J = 256 / C;                       // threads per coefficient (C <= 32: J >= 8)
+        const int c = tid / J, j = tid - c * J;
+        const bool mine = c < C;
         double a = 0.0;
-        for (int t = lane; t < T; t += 64) a += (double)(float)(in((int64_t)t * ld_in + c, c) - gmean);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-        const double mu = T > 0 ? a / (double)T : 0.0;
-        double v = 0.0;
-        for (int t = lane; t < T; t += 64) {
-            const double dlt = (double)(float)(in((int64_t)t * ld_in + c, c) - gmean) - mu;
-            v += dlt * dlt;
+        if (mine)
+            for (int t = j; t < T; t += J) a += (double)(float)(in((int64_t)t * ld_in + c, c) - gmean);
+        s_part[tid] = a;
+        __syncthreads();
+        if (mine && j == 0) {
+            double tot = 0.0;
+            for (int k = 0; k < J; ++k) tot += s_part[c * J + k];
+            s_mu[c] = T > 0 ? tot / (double)T : 0.0;
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (lane == 0) {
-            const double sd = T > 0 ? sqrt(v / (double)T) : 0.0;
-            s_mu[c] = mu;
+        __syncthreads();
+        double v = 0.0;
+        if (mine) {
+            const double mu = s_mu[c];
+            for (int t = j; t < T; t += J) {
+                const double dlt = (double)(float)(in((int64_t)t * ld_in + c, c) - gmean) - mu;
+                v += dlt * dlt;
+            }
+        }
+        s_part[tid] = v;
+        __syncthreads();
+        if (mine && j == 0) {
+            double tot = 0.0;
+            for (int k = 0; k < J; ++k) tot += s_part[c * J + k];
+            const double sd = T > 0 ? sqrt(tot / (double)T) : 0.0;
             s_inv[c] = sd == 0.0 ? 1.0 : 1.0 / sd;
         }
     }
