@@ -304,11 +304,13 @@ def test_vad_tile_kernel_vs_per_frame_kernel_and_oracle(rate, dtype):
         assert list(tile[1][fo_r[b]:fo_r[b + 1]]) == list(dsp_oracle.get_zcr(frames))
 
 
-@pytest.mark.parametrize('rate', [16000, 48000, 8000])
+@pytest.mark.parametrize('rate', [16000, 48000, 8000, 44100, 11025, 32000, 22050])
 def test_vad_int16_extreme_values_are_exact(rate):
     """The integer amplitude / zero-crossing kernel (vad_scan_kernel) at the ends of the int16 range: every sample
     -32768 (the largest per-vector sum, no crossing), +32767 / -32768 alternating (a crossing at every pair), runs of
-    zeros between opposite signs (never a crossing), ragged lengths and odd sample offsets.  Every value exact."""
+    zeros between opposite signs (never a crossing), ragged lengths and odd sample offsets.  Every value exact.  At 44.1,
+    22.05 and 11.025 kHz frames are not whole 4-sample vectors (1323 / 441, 661 / 220, 330 / 110 samples): the kernel adds
+    up to three samples in front of and behind a frame's whole vectors one by one."""
     from features.batch import EndpointPlan
     ep = EndpointPlan(rate, 0.03, 0.01)
     rng = np.random.default_rng(5)
