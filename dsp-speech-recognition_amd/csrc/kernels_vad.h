@@ -493,8 +493,7 @@ __global__ __launch_bounds__(64 * VAD_WAVES) void vad_scan_kernel(VadParams P, B
         const int16_t* gp = wave + s0 + base;
         // Frame `lane` = samples [flo, fhi) of the group = the whole vectors [vlo, vhi) plus up to three samples in front
         // and three behind (none when L and S are multiples of 4).  The lane reads those few, and the sample in front of
-        // each run, itself: x[flo - 1 .. flo + 2] and x[4 vhi - 1 .. 4 vhi + 2], zeros outside the clip (idle lanes read
-        // the group's first sample).  Used in the frame phase, so nothing waits for them here.
+        // each run, itself: x[flo - 1 .. flo + 2] and x[4 vhi - 1 .. 4 vhi + 2], zeros outside the clip.  Used in the frame phase, so nothing waits for them here.
         const int flo = lane * P.S, fhi = flo + P.L;
         const int vlo = (flo + 3) >> 2, vhi = fhi >> 2;
         int hw[4], tw[4];
@@ -502,8 +501,11 @@ __global__ __launch_bounds__(64 * VAD_WAVES) void vad_scan_kernel(VadParams P, B
         for (int k = 0; k < 4; ++k) {
             const int ih = flo - 1 + k, it = 4 * vhi - 1 + k;
             const bool okh = lane < FR && ih >= 0 && base + ih < nsamp, okt = lane < FR && base + it < nsamp;
-            hw[k] = gp[okh ? ih : 0];
-            tw[k] = gp[okt ? it : 0];
+            // (lanes with nothing to read load from the result buffer instead -- always mapped, value dropped: the clip
+            //  itself may be empty, and an empty LAST clip has no valid sample address at all)
+            const int16_t* const idle = reinterpret_cast<const int16_t*>(amp_sum);
+            hw[k] = *(okh ? gp + ih : idle);
+            tw[k] = *(okt ? gp + it : idle);
             hw[k] = okh ? hw[k] : 0;
             tw[k] = okt ? tw[k] : 0;
         }

@@ -320,7 +320,9 @@ def test_vad_int16_extreme_values_are_exact(rate):
              np.where(np.arange(n) % 3 == 0, 0, np.where(np.arange(n) % 2 == 0, 1, -1)).astype(np.int16),
              rng.integers(-32768, 32768, n // 2 + 1).astype(np.int16),
              rng.integers(-2, 3, ep.L + 3 * ep.S + 1).astype(np.int16),
-             np.array([5], dtype=np.int16)]
+             np.zeros(0, dtype=np.int16),                       # an empty clip is one frame of zeros (sigproc.py:11-19)
+             np.array([5], dtype=np.int16),
+             np.zeros(0, dtype=np.int16)]                       # ... and so is an empty LAST clip: no sample address at all
     so = np.concatenate([[0], np.cumsum([len(c) for c in clips])]).astype(np.int64)
     _, amp, zcr, fo = ep.detect_batch(np.concatenate(clips), sample_offsets=so, return_feature=True)
     for b, c in enumerate(clips):
