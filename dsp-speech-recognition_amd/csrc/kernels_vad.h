@@ -417,9 +417,9 @@ __global__ __launch_bounds__(64 * VAD_WAVES) void vad_sum_kernel(VadParams P, Ba
 
 // int16 input, sum |x|, ANY frame length and hop -- the endpoint path's standard case (16-bit wav data, get_amplitude and
 // get_zcr of endpoint.py:109-126, 182-198; 30 ms / 10 ms frames are 480 / 160 samples at 16 kHz, 1323 / 441 at 44.1 kHz)
-// -- in integer arithmetic on packed halves, a third of vad_sum_kernel's vector instructions (it was issue bound: 811
-// vector instructions per group of 16 frames, 18 us per 49 MB; vad_vec_kernel, which served the frames that are not
-// whole vectors, 54 us per 69 MB):
+// -- in integer arithmetic on packed halves: 473 vector instructions per group of 16 frames where vad_sum_kernel issued
+// 811 (it was issue bound, 18 us per 49 MB; vad_vec_kernel, which served the frames that are not whole vectors, took 54 us
+// per 69 MB):
 //   * per 4-sample vector (two dwords w0 = x1:x0, w1 = x3:x2): sgn = clamp(x, -1, 1) on both halves (v_pk_min / max_i16),
 //     |x0| + .. + |x3| = two v_dot2_i32_i16 of (x, sgn); the sign changes of the pairs (x[i-1], x[i]) are the halves
 //     equal to -1 of sgn x (sgn shifted by one sample: v_alignbit over the previous dword, the previous LANE's last
