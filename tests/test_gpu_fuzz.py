@@ -364,3 +364,41 @@ def test_device_pitch_tracker_equals_the_reference_sequence():
             want = np.asarray(robust_max_pitch(smooth(sc[fo[b]:fo[b + 1]].astype(np.float64), 2), bias=20))
         assert np.array_equal(got[fo[b]:fo[b + 1]], want), (b, T, np.argwhere(got[fo[b]:fo[b + 1]] != want)[:5])
     assert lib.dsp_pitch_track_batch(d_sc.ptr, d_fo.ptr, len(Ts), n_lags, 20, 3, d_p.ptr, None) == -1
+
+
+def test_vad_kernel_at_random_frame_lengths_and_hops():
+    """dsp_vad_features_batch on int16 clips at 24 random (frame length, hop) pairs of either parity -- whole vectors, odd
+    hops, hops longer than a quarter of the frame, frames a few vectors long -- against sums formed in NumPy on frames cut
+    as sigproc.to_frames cuts them (sigproc.py:11-19).  Every amplitude sum and every zero-crossing count exact."""
+    from features import _native as nat
+    lib = nat.load()
+    rng = np.random.default_rng(77)
+    for case in range(24):
+        L = int(rng.integers(64, 1500)) if case % 3 else 4 * int(rng.integers(16, 360))
+        S = int(rng.integers(max(8, L // 6), L + 1)) if case % 4 else 4 * int(rng.integers(4, L // 4 + 1))
+        lens = [int(rng.integers(1, 6 * L)) for _ in range(7)] + [L, L + 1, L + S, L - 1, 1]
+        clips = [rng.integers(-32768, 32768, n).astype(np.int16) if k % 3 else rng.integers(-3, 4, n).astype(np.int16)
+                 for k, n in enumerate(lens)]
+        so = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        fo = nat.frame_offsets(so, L, S)
+        flat = np.concatenate(clips)
+        d_x = nat.DeviceBuffer(flat.nbytes).upload(flat)
+        d_so = nat.DeviceBuffer(so.nbytes).upload(so)
+        d_fo = nat.DeviceBuffer(fo.nbytes).upload(fo)
+        d_amp = nat.DeviceBuffer(int(fo[-1]) * 8)
+        d_zcr = nat.DeviceBuffer(int(fo[-1]) * 4)
+        nat.check(lib.dsp_vad_features_batch(d_x.ptr, nat.WAVE_I16, d_so.ptr, d_fo.ptr, len(lens), int(fo[-1]), 0, L, S, 0,
+                                             d_amp.ptr, d_zcr.ptr, None))
+        amp = d_amp.download((int(fo[-1]),), np.float64)
+        zcr = d_zcr.download((int(fo[-1]),), np.int32)
+        for b, c in enumerate(clips):
+            n = len(c)
+            T = 1 if n <= L else 1 + -(-(n - L) // S)
+            assert fo[b + 1] - fo[b] == T, (L, S, n)
+            x = np.zeros((T - 1) * S + L, dtype=np.int64)
+            x[:n] = c
+            fr = np.stack([x[t * S:t * S + L] for t in range(T)])
+            want_amp = np.abs(fr).sum(1).astype(np.float64)
+            want_zcr = ((fr[:, 1:] * fr[:, :-1]) < 0).sum(1)
+            assert np.array_equal(amp[fo[b]:fo[b + 1]], want_amp), (case, L, S, b, n)
+            assert np.array_equal(zcr[fo[b]:fo[b + 1]], want_zcr), (case, L, S, b, n)
