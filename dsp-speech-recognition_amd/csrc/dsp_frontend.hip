@@ -662,6 +662,8 @@ struct dsp_layout {
     int64_t n_frames_total;
     int32_t* group_off;
     int32_t* group_utt;
+    int32_t* group_off2;   // tables of the int16 VAD kernel's 8-frame groups, where it uses them (vad_scan_frames8)
+    int32_t* group_utt2;
     int device;
 };
 
@@ -687,12 +689,20 @@ int dsp_layout_create(const int64_t* d_frame_offsets, int32_t n_utt, int64_t n_f
         l->shift = tile == 16 ? 4 : 2;
         const int64_t bound = n_frames_total / tile + n_utt;
         if (bound > 0x3fffffff) { delete l; return fail(DSP_EINVAL, "dsp_layout_create: batch too large"); }
-        if (hipMalloc(reinterpret_cast<void**>(&l->group_off), ((size_t)n_utt + 1 + (size_t)bound) * sizeof(int32_t)) != hipSuccess) {
+        const bool second = vad_scan_frames8(frame_len, frame_step, DSP_WAVE_I16, 0);      // int16 callers take 8-frame groups
+        const int64_t bound2 = second ? n_frames_total / 8 + n_utt : 0;
+        const size_t n1 = (size_t)n_utt + 1 + (size_t)bound, n2 = second ? (size_t)n_utt + 1 + (size_t)bound2 : 0;
+        if (hipMalloc(reinterpret_cast<void**>(&l->group_off), (n1 + n2) * sizeof(int32_t)) != hipSuccess) {
             delete l;
             return fail(DSP_EHIP, "dsp_layout_create: allocation failed");
         }
         l->group_utt = l->group_off + n_utt + 1;
         f512_build_group_tables(d_frame_offsets, n_utt, l->shift, l->group_off, l->group_utt, (hipStream_t)stream);
+        if (second) {
+            l->group_off2 = l->group_off + n1;
+            l->group_utt2 = l->group_off2 + n_utt + 1;
+            f512_build_group_tables(d_frame_offsets, n_utt, 3, l->group_off2, l->group_utt2, (hipStream_t)stream);
+        }
         if (hipGetLastError() != hipSuccess) { (void)hipFree(l->group_off); delete l; return fail(DSP_EHIP, "dsp_layout_create: launch failed"); }
     }
     *out = l;
@@ -746,7 +756,10 @@ static int vad_features_impl(const dsp_layout* layout, const void* d_wave, int w
         const bool ok = vad_tile_applicable(fg, fw, wave_dtype, tile);
         DspRaggedTables pre;
         const bool have_pre = layout != nullptr && layout->group_off != nullptr && view == nullptr;
-        if (have_pre) { pre.shift = layout->shift; pre.group_off = layout->group_off; pre.group_utt = layout->group_utt; }
+        if (have_pre) {
+            pre.shift = layout->shift; pre.group_off = layout->group_off; pre.group_utt = layout->group_utt;
+            if (layout->group_off2 != nullptr) { pre.shift2 = 3; pre.group_off2 = layout->group_off2; pre.group_utt2 = layout->group_utt2; }
+        }
         if (ok) rc = vad_tile_launch(tile, frame_len, frame_step, use_sq, fg, fw, wave_dtype, d_amp_sum, d_zcr, st,
                                      have_pre ? &pre : nullptr);
         if (view && dsp_workspace_pool().release(view, st) != 0 && ok && rc == DSP_OK) rc = DSP_EHIP;

@@ -1504,6 +1504,11 @@ struct DspRaggedTables {
     int32_t* group_off = nullptr;   // [n_utt + 1] prefix of ceil(T_b / 2^shift)
     int32_t* group_utt = nullptr;   // utterance of every group
     int shift = 0;                  // 3: NFFT=512 kernel (8 frames per wave), 2: NFFT=1536 kernel
+    // a second set for another group size (a dsp_layout holds the tables of the int16 VAD kernel's 8-frame groups beside
+    // those of the 4-frame groups the other VAD kernels use, when the two differ)
+    int32_t* group_off2 = nullptr;
+    int32_t* group_utt2 = nullptr;
+    int shift2 = 0;
 };
 
 template <int NROWS, int NI, int CAPS, int NSTAGE>
