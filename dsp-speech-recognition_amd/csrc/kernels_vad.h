@@ -449,9 +449,9 @@ __global__ __launch_bounds__(64 * VAD_WAVES) void vad_scan_kernel(VadParams P, B
                                                                   double* __restrict__ amp_sum,
                                                                   int32_t* __restrict__ zcr) {
     constexpr int SHIFT = FR == 16 ? 4 : (FR == 8 ? 3 : 2);
-    // eight frames per wave (7 S + L samples: 4410 at 44.1 kHz) stage 18 rounds of 64 vectors; a lane stride of 20 dwords in
-    // the prefix phase is conflict free for 16-byte reads like the stride of 12
-    constexpr int NS = FR == 8 ? 18 : VAD_NSTAGE, CH = FR == 8 ? 20 : VAD_SCAN_CH;
+    // eight frames per wave (7 S + L samples: 4410 at 44.1 kHz, 4800 at 48 kHz) stage up to 20 rounds of 64 vectors; a lane
+    // stride of 20 dwords in the prefix phase is conflict free for 16-byte reads like the stride of 12
+    constexpr int NS = FR == 8 ? 20 : VAD_NSTAGE, CH = FR == 8 ? 20 : VAD_SCAN_CH;
     static_assert(CH * 64 >= NS * 64 && CH % 4 == 0, "the prefix phase covers every staged vector");
     extern __shared__ __attribute__((aligned(256))) float smem_f[];
     const int tid = threadIdx.x;
@@ -642,12 +642,12 @@ static inline int vad_tile_frames(int32_t L, int32_t S) {
     return 0;
 }
 
-// int16, sum |x|: does vad_scan_kernel take this framing with EIGHT frames per wave (18 rounds of 64 vectors)?  Only where
+// int16, sum |x|: does vad_scan_kernel take this framing with EIGHT frames per wave (up to 20 rounds of 64 vectors)?  Only where
 // sixteen do not fit and four would otherwise be used.
 static inline bool vad_scan_frames8(int32_t L, int32_t S, int dtype, int32_t use_sq) {
     if (dtype != DSP_WAVE_I16 || use_sq || L < 64 || S < 1) return false;
     if ((15 * (int64_t)S + L + 3) / 4 + 1 <= 64 * VAD_NSTAGE) return false;      // sixteen frames per wave fit
-    return (7 * (int64_t)S + L + 3) / 4 <= 64 * 18 && (3 * (int64_t)S + L + 3) / 4 + 1 <= 64 * VAD_NSTAGE;
+    return (7 * (int64_t)S + L + 3) / 4 <= 64 * 20 && (3 * (int64_t)S + L + 3) / 4 + 1 <= 64 * VAD_NSTAGE;
 }
 
 static inline bool vad_tile_applicable(const BatchGeom& bg, const void* d_wave, int dtype, int FR) {
@@ -792,7 +792,7 @@ static inline int vad_tile_launch(int FR, int32_t L, int32_t S, int32_t use_sq, 
     P.L = L; P.S = S; P.use_sq = use_sq;
     if (FR == 16) return vad_tile_launch_t<16>(P, bg, d_wave, dtype, d_amp, d_zcr, st, pre);
     // int16 clips whose 16-frame groups do not fit (44.1 kHz: 30 ms / 10 ms = 1323 / 441 samples): eight frames per wave
-    // (1103 of 1152 staged vectors) instead of four -- 1.25 x instead of 1.5 x of the samples read, half the prefix-scan
+    // (1103 of 1280 staged vectors; 1200 at 48 kHz) instead of four -- 1.25 x instead of 1.5 x of the samples read, half the prefix-scan
     // work per frame: 23.4 vs 30.0 us per 69 MB (same-job A/B)
     if (vad_scan_frames8(L, S, dtype, use_sq)) {
         static const bool no_scan = getenv("DSP_VAD_NOSCAN") != nullptr;
